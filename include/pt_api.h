@@ -1,0 +1,165 @@
+/*
+ * pt_api.h -- C ABI of libpt_hip.so, the MI355X (gfx950) implementation of the
+ * point-based detail-transfer hot path of
+ * horizon-research/3D-Reconstruction-From-Point-Cloud.
+ *
+ * The reference has no FFI / plugin layer: its hot path is inline
+ * code in main().  Each entry point below names the reference lines it replaces;
+ * INTEGRATION.md shows the patch a maintainer applies to src/pointsTransfer.cpp.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative pt_status otherwise; nothing
+ *     throws across the boundary; pt_last_error() gives the text of the last failure;
+ *   - the caller owns every buffer; nothing passed in is retained after return unless
+ *     stated ("_dev" functions read device pointers during the call only);
+ *   - one context per calling thread and per GPU (one process per GPU for multi-GPU);
+ *   - neighbours of a target are returned ascending under the total order
+ *     (d2 as IEEE double, original index as uint32) with
+ *       d2 = (dx*dx + dy*dy) + dz*dz,  dx = (double)t.x - (double)p.x,  no FMA
+ *     -- bit-for-bit src/Distance.h:6-11 as the reference's Release flags compile it;
+ *   - `idx` values are positions in the caller's ORIGINAL cloud order (or the global
+ *     indices given to pt_build_soa_indexed); missing neighbours (k > N) are
+ *     PT_NOIDX with d2 = +inf;
+ *   - planar xyz: `xyz` points at 3*n elements, x[0..n) then y[0..n) then z[0..n).
+ *   - there is NO CPU fallback: every compute entry point fails with PT_ERR_HIP when no
+ *     gfx950 device is usable.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_NOIDX 0xFFFFFFFFu
+#define PT_MAX_K 32
+
+typedef enum {
+  PT_OK = 0,
+  PT_ERR_ARG = -1,      /* bad argument (null pointer, k out of range, n too large ...) */
+  PT_ERR_HIP = -2,      /* HIP runtime error / no device */
+  PT_ERR_STATE = -3,    /* call order (query before build ...) */
+  PT_ERR_NOMEM = -4,    /* device allocation failed */
+  PT_ERR_UNSUPPORTED = -5
+} pt_status;
+
+typedef enum { PT_F32 = 0, PT_F16 = 1, PT_F64 = 2 } pt_xyz_type;
+typedef enum { PT_DIST_UNIFORM = 0, PT_DIST_CLUSTERED = 1 } pt_synth_dist;
+typedef enum { PT_BLEND_MEAN = 0, PT_BLEND_INV_D2 = 1 } pt_blend_mode;
+
+/* The reference's record (src/Point.h:1-6), sizeof == 80, offsets 0/24/48/64/72.
+ * include/Point.h carries the C++ struct with the reference's member functions;
+ * this POD twin is what crosses the C boundary. */
+typedef struct pt_point {
+  double ver[3];
+  double normal[3];
+  int32_t color[3];
+  int32_t _pad;
+  double U;
+  double V;
+} pt_point;
+
+typedef struct pt_ctx pt_ctx;
+
+/* per-phase device timings (HIP events on the context's stream) and byte accounting */
+typedef struct pt_stats_t {
+  uint64_t n_source, n_target; int32_t k, _pad;
+  double ms_build;          /* grid build over the source cloud (last build) */
+  double ms_sort_targets;   /* target binning (last query) */
+  double ms_query;          /* k-NN kernel (last query) */
+  double ms_blend;          /* attribute gather + blend (last blend) */
+  double ms_pca;            /* PCA normals (last pca) */
+  uint64_t bytes_alg_build; /* N*(2s+4) */
+  uint64_t bytes_alg_query; /* N*s + M*s + M*k*16 + M*(4k+24) */
+  int32_t grid_dim[3];      /* cells per axis */
+  int32_t n_levels;         /* partition passes used by the build (1 or 2) + finalize */
+  double cell_size;
+  uint64_t n_cells;
+  uint64_t device_bytes;    /* bytes currently allocated by the context */
+} pt_stats_t;
+
+/* ---- context ------------------------------------------------------------------------ */
+/* device_ids[0] is the GPU this context runs on (one process per GPU); n_devices must be 1. */
+int  pt_ctx_create(pt_ctx** out, const int* device_ids, int n_devices);
+void pt_ctx_destroy(pt_ctx*);
+/* Plumbing: run all work of this context on the caller's hipStream_t (e.g. torch's current
+ * stream).  NULL = the context's own stream. */
+int  pt_set_stream(pt_ctx*, void* hip_stream);
+/* Tunables: "rho" (target points per grid cell, default 8), "sync" (1 = every call blocks until
+ * the GPU is done, default 1; 0 = _dev calls only enqueue). */
+int  pt_set_param(pt_ctx*, const char* name, double value);
+const char* pt_last_error(pt_ctx*);
+int  pt_stats(pt_ctx*, pt_stats_t* out);
+int  pt_synchronize(pt_ctx*);
+
+/* ---- build: replaces `Tree tree(points.begin(), points.end())`, pointsTransfer.cpp:259 ---- */
+/* AoS reference records on the host (80-B stride); coordinates are kept as double on the GPU. */
+int  pt_build_aos(pt_ctx*, const pt_point* cloud, uint64_t n);
+/* Planar xyz of `xyz_type` (+ optional interleaved rgb u8[n][3] and normals f32[n][3]); host or
+ * device memory according to on_device. */
+int  pt_build_soa(pt_ctx*, const void* xyz, int xyz_type, const uint8_t* rgb, const float* nrm,
+                  uint64_t n, int on_device);
+/* Same, for one spatial slab of a larger cloud: gidx[i] is the point's index in the whole cloud
+ * (what queries return); attributes stay indexed by that global index, see pt_set_attributes. */
+int  pt_build_soa_indexed(pt_ctx*, const void* xyz, int xyz_type, const uint32_t* gidx, uint64_t n,
+                          int on_device);
+/* Attribute table indexed by global index (the whole cloud's, on every GPU). */
+int  pt_set_attributes(pt_ctx*, const uint8_t* rgb, const float* nrm, uint64_t n_total, int on_device);
+/* SURVEY.md Appendix C generator, on the device.  Keeps the points whose coordinate along
+ * `slab_axis` lies in [slab_lo, slab_hi) (pass -inf/+inf, or slab_axis < 0, for the whole cloud);
+ * indices stay global; the attribute table is generated for all n_total points. */
+int  pt_build_synth(pt_ctx*, uint64_t n_total, uint64_t seed, int dist, int xyz_type,
+                    int slab_axis, double slab_lo, double slab_hi);
+/* Re-run the grid build over the resident source cloud (what a bench step times). */
+int  pt_rebuild(pt_ctx*);
+uint64_t pt_num_source(pt_ctx*);        /* points resident in this context (slab-local) */
+
+/* ---- query: replaces the K_neighbor_search loop, pointsTransfer.cpp:462-479 ---------------- */
+int  pt_query_aos(pt_ctx*, const pt_point* targets, uint64_t m, int k, uint32_t* idx, double* d2_or_null);
+int  pt_query_soa(pt_ctx*, const void* xyz, int xyz_type, uint64_t m, int k, int on_device,
+                  uint32_t* idx, double* d2_or_null);
+/* Generate m targets on the device (stream 1 of the generator) into the context; query them with
+ * pt_query_resident.  tgt_lo/hi restrict to targets whose slab_axis coordinate is in [lo,hi). */
+int  pt_targets_synth(pt_ctx*, uint64_t m_total, uint64_t seed, int dist, int xyz_type,
+                      int slab_axis, double slab_lo, double slab_hi);
+uint64_t pt_num_targets(pt_ctx*);
+/* Query the resident targets; idx/d2 are DEVICE buffers of m*k entries (d2 may be NULL). */
+int  pt_query_resident(pt_ctx*, int k, uint32_t* idx_dev, double* d2_dev_or_null);
+/* Global index (position in the whole target set) of each resident target, device u32[m]. */
+int  pt_resident_target_ids(pt_ctx*, uint32_t* ids_dev);
+/* Planar xyz (f32 or f64 as generated) of the resident targets, copied to a device buffer. */
+int  pt_resident_target_xyz(pt_ctx*, void* xyz_dev);
+
+/* ---- blend: the only blend arithmetic of the reference is pointsTransfer.cpp:95-97 --------- */
+/* host buffers in / out */
+int  pt_blend(pt_ctx*, const uint32_t* idx, const double* d2_or_null, uint64_t m, int k, int mode,
+              float* rgb_out, float* nrm_out);
+/* device buffers in / out */
+int  pt_blend_dev(pt_ctx*, const uint32_t* idx_dev, const double* d2_dev_or_null, uint64_t m, int k,
+                  int mode, float* rgb_out_dev, float* nrm_out_dev);
+/* PCA normal of the k neighbours (BASELINE config 3); needs the whole cloud resident (no slabs). */
+int  pt_pca_normals(pt_ctx*, const uint32_t* idx, uint64_t m, int k, float* nrm_out);
+int  pt_pca_normals_dev(pt_ctx*, const uint32_t* idx_dev, uint64_t m, int k, float* nrm_out_dev);
+
+/* ---- multi-GPU merge ---------------------------------------------------------- */
+/* G-way merge of candidate lists under (d2, idx): lists are [g][m][k] device arrays. */
+int  pt_merge_candidates_dev(pt_ctx*, const uint32_t* idx_lists_dev, const double* d2_lists_dev, int g,
+                             uint64_t m, int k, uint32_t* idx_out_dev, double* d2_out_dev);
+/* For each target t and each slab s != my_slab, need[s*m + t] = 1 iff slab s can still hold one of
+ * t's k nearest: dist2(t, slab interval) <= d2[t][k-1], or the list is not full.  This is
+ * Distance::min_distance_to_rectangle (src/Distance.h:27-57) applied to slab boxes.
+ * slab_bounds: G+1 ascending doubles on the host. */
+int  pt_slab_need_dev(pt_ctx*, const void* tgt_xyz_dev, int xyz_type, const double* d2_dev, uint64_t m, int k,
+                      int slab_axis, const double* slab_bounds, int g, int my_slab, uint8_t* need_dev);
+/* Bounded query for foreign targets: like pt_query_soa(on_device=1) but each target starts from the
+ * radius bound2[t] (its current k-th squared distance; +inf = unbounded): only points with
+ * d2 <= bound2[t] are returned. */
+int  pt_query_bounded_dev(pt_ctx*, const void* xyz_dev, int xyz_type, const double* bound2_dev, uint64_t m,
+                          int k, uint32_t* idx_dev, double* d2_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_API_H */
