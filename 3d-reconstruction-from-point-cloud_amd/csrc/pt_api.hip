@@ -1,0 +1,655 @@
+// pt_api.hip -- the extern "C" boundary of libpt_hip.so (declared in include/pt_api.h) and the
+// context that owns every HBM allocation of the detail-transfer path on one MI355X.
+//
+// Call sites this replaces in the reference (INTEGRATION.md has the patch):
+//   pt_build_*   <->  Tree tree(points.begin(), points.end());           src/pointsTransfer.cpp:259
+//   pt_query_*   <->  K_neighbor_search search(tree, v, K) + iteration    src/pointsTransfer.cpp:462-479
+//   pt_stats     <->  the timer lines                                     src/pointsTransfer.cpp:261,587
+// There is no CPU fallback anywhere in this file: without a usable HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+
+#include "../../include/pt_api.h"
+#include "pt_internal.h"
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct pt_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::string err;
+  double rho = 8.0;
+  int sync = 1;
+  size_t dev_bytes = 0;
+
+  // source cloud (slab-local when built from a slab)
+  int src_type = -1;           // PT_F32 / PT_F64
+  uint64_t n = 0, n_total = 0; // resident points; size of the attribute table
+  DevBuf in_xyz, in_gidx, attr, rec, rec_tmp, cell_start;
+  bool has_gidx = false, has_attr = false, built = false;
+  GridParams gp{};
+  SortTables stb{};
+  DevBuf stb_mem;
+
+  // resident targets
+  int tgt_type = -1;
+  uint64_t m = 0;
+  DevBuf t_xyz, t_gidx, trec, trec_tmp;
+  bool t_has_gidx = false;
+  SortTables ttb{};
+  DevBuf ttb_mem;
+
+  // scratch
+  DevBuf bbox6, counter, q_idx, q_d2, b_rgb, b_nrm, aos_stage, misc, bounds;
+  uint64_t* h_bbox = nullptr;   // pinned
+  uint32_t* h_counter = nullptr;
+
+  pt_stats_t st{};
+};
+
+namespace {
+
+int fail(pt_ctx* c, int code, const char* fmt, ...) {
+  if (c) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    c->err = buf;
+  }
+  return code;
+}
+#define HIPCHK(c, call)                                                                                     \
+  do {                                                                                                      \
+    hipError_t e_ = (call);                                                                                 \
+    if (e_ != hipSuccess) return fail((c), PT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+int reserve(pt_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return PT_OK;
+  if (b.p) { (void)hipFree(b.p); c->dev_bytes -= b.cap; b.p = nullptr; b.cap = 0; }
+  if (bytes == 0) bytes = 16;
+  bytes = (bytes + 255) & ~(size_t)255;
+  hipError_t e = hipMalloc(&b.p, bytes);
+  if (e != hipSuccess) { b.p = nullptr; return fail(c, PT_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
+  b.cap = bytes;
+  c->dev_bytes += bytes;
+  return PT_OK;
+}
+void release(pt_ctx* c, DevBuf& b) {
+  if (b.p) { (void)hipFree(b.p); c->dev_bytes -= b.cap; }
+  b.p = nullptr; b.cap = 0;
+}
+#define RES(c, buf, bytes)                       \
+  do {                                           \
+    int r_ = reserve((c), (buf), (bytes));       \
+    if (r_ != PT_OK) return r_;                  \
+  } while (0)
+
+size_t tsize(int t) { return t == PT_F64 ? 8 : 4; }
+size_t recsize(int t) { return t == PT_F64 ? sizeof(RecD) : sizeof(RecF); }
+
+int finish(pt_ctx* c) {
+  if (c->sync) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PT_OK;
+}
+
+// carve the SortTables of one sort out of a single allocation
+int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks) {
+  const size_t small = PT_MAXBINS + 8;
+  const size_t words = small * 4 /*counts1,start1,cursor1,tile_first2*/ + 16 /*tile_first1, seg_start1*/ +
+                       ((size_t)nblocks + 8) * 3 + ((size_t)nblocks / 2048 + 16);
+  RES(c, mem, words * sizeof(uint32_t));
+  uint32_t* p = (uint32_t*)mem.p;
+  tb.counts1 = p; p += small;
+  tb.start1 = p; p += small;
+  tb.cursor1 = p; p += small;
+  tb.tile_first2 = p; p += small;
+  tb.tile_first1 = p; p += 8;
+  tb.seg_start1 = p; p += 8;
+  tb.block_count = p; p += (size_t)nblocks + 8;
+  tb.block_start = p; p += (size_t)nblocks + 8;
+  tb.cursor2 = p; p += (size_t)nblocks + 8;
+  tb.scan_tmp = p;
+  return PT_OK;
+}
+
+// choose the grid from the bounding box: cubic cells of side h with about rho points each
+void choose_grid(pt_ctx* c, const double mn[3], const double mx[3]) {
+  GridParams& g = c->gp;
+  double ext[3], maxext = 0.0;
+  for (int a = 0; a < 3; ++a) { ext[a] = mx[a] - mn[a]; if (!(ext[a] >= 0)) ext[a] = 0; maxext = std::max(maxext, ext[a]); }
+  double h = 1.0;
+  if (maxext > 0 && c->n > 0) {
+    double vol = 1.0;
+    for (int a = 0; a < 3; ++a) vol *= std::max(ext[a], maxext * 1e-6);
+    h = std::cbrt(vol * c->rho / (double)c->n);
+    if (!(h > 0) || !std::isfinite(h)) h = maxext;
+    h = std::max(h, maxext / 60000.0);     // <= ~2^16 cells per axis
+  }
+  for (;;) {
+    const double inv_h = 1.0 / h;
+    uint64_t nmacro = 1;
+    for (int a = 0; a < 3; ++a) {
+      g.bbmin[a] = mn[a];
+      const double cells = std::ceil(ext[a] * inv_h);
+      g.dim[a] = (int)std::max(1.0, std::min(cells, 1.0e6));
+      g.mdim[a] = (g.dim[a] + 63) / 64;
+      nmacro *= (uint64_t)g.mdim[a];
+    }
+    g.inv_h = inv_h;
+    g.h = h;
+    if (nmacro <= PT_MAXBINS) { g.nblocks = (int)(nmacro * PT_MACRO_BLOCKS); break; }
+    h *= 1.2599210498948732;   // too many macro blocks for one partition pass: double the cell volume
+  }
+}
+
+template <class T, class Rec>
+int run_source_sort(pt_ctx* c) {
+  const T* x = (const T*)c->in_xyz.p;
+  pt_launch_grid_sort<T, Rec>(c->gp, x, x + c->n, x + 2 * c->n, c->has_gidx ? (const uint32_t*)c->in_gidx.p : nullptr, (uint32_t)c->n,
+                              (Rec*)c->rec.p, (Rec*)c->rec_tmp.p, (uint32_t*)c->cell_start.p, c->stb, c->stream);
+  return PT_OK;
+}
+
+int rebuild(pt_ctx* c) {
+  if (c->src_type != PT_F32 && c->src_type != PT_F64) return fail(c, PT_ERR_STATE, "no source cloud resident (call a pt_build_* first)");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  if (c->n) {
+    pt_launch_bbox_init((uint64_t*)c->bbox6.p, c->stream);
+    if (c->src_type == PT_F32) { const float* x = (const float*)c->in_xyz.p; pt_launch_bbox<float>(x, x + c->n, x + 2 * c->n, (uint32_t)c->n, (uint64_t*)c->bbox6.p, c->stream); }
+    else { const double* x = (const double*)c->in_xyz.p; pt_launch_bbox<double>(x, x + c->n, x + 2 * c->n, (uint32_t)c->n, (uint64_t*)c->bbox6.p, c->stream); }
+    HIPCHK(c, hipMemcpyAsync(c->h_bbox, c->bbox6.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int a = 0; a < 3; ++a) { mn[a] = pt_bbox_decode(c->h_bbox[a]); mx[a] = pt_bbox_decode(c->h_bbox[3 + a]); }
+    for (int a = 0; a < 3; ++a)
+      if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) return fail(c, PT_ERR_ARG, "source coordinates are not finite");
+  }
+  choose_grid(c, mn, mx);
+  const uint32_t nblocks = (uint32_t)c->gp.nblocks;
+  const size_t ncells = (size_t)nblocks * PT_BLOCK_CELLS;
+  RES(c, c->cell_start, (ncells + 1) * sizeof(uint32_t));
+  RES(c, c->rec, std::max<size_t>(c->n, 1) * recsize(c->src_type));
+  RES(c, c->rec_tmp, std::max<size_t>(c->n, 1) * recsize(c->src_type));
+  { int r = make_tables(c, c->stb_mem, c->stb, nblocks); if (r != PT_OK) return r; }
+  if (c->src_type == PT_F32) run_source_sort<float, RecF>(c); else run_source_sort<double, RecD>(c);
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  HIPCHK(c, hipGetLastError());
+  c->built = true;
+  c->st.n_source = c->n;
+  c->st.grid_dim[0] = c->gp.dim[0]; c->st.grid_dim[1] = c->gp.dim[1]; c->st.grid_dim[2] = c->gp.dim[2];
+  c->st.cell_size = c->gp.h;
+  c->st.n_cells = ncells;
+  c->st.n_levels = nblocks <= PT_MAXBINS ? 1 : 2;
+  const uint64_t s = tsize(c->src_type) * 3;
+  c->st.bytes_alg_build = c->n * (2 * s + 4);
+  if (c->sync) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->st.ms_build = ms;
+  }
+  return PT_OK;
+}
+
+int check_n(pt_ctx* c, uint64_t n, const char* what) {
+  if (n >= 0xFFFFFFF0ull) return fail(c, PT_ERR_ARG, "%s = %llu does not fit 32-bit indices", what, (unsigned long long)n);
+  return PT_OK;
+}
+
+int copy_in(pt_ctx* c, void* dst, const void* src, size_t bytes, int on_device) {
+  if (!bytes) return PT_OK;
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  if (!on_device) HIPCHK(c, hipStreamSynchronize(c->stream));   // pageable host memory: the caller may reuse it on return
+  return PT_OK;
+}
+
+// sort the resident targets into cell order and run the k-NN kernel
+int query_resident(pt_ctx* c, int k, const double* bound2_dev, uint32_t* idx_dev, double* d2_dev) {
+  if (!c->built) return fail(c, PT_ERR_STATE, "query before build");
+  if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k = %d out of range [1, %d]", k, PT_MAX_K);
+  if (c->tgt_type != c->src_type) return fail(c, PT_ERR_UNSUPPORTED, "target xyz type %d differs from the source cloud's %d", c->tgt_type, c->src_type);
+  if (!idx_dev && c->m) return fail(c, PT_ERR_ARG, "idx output is null");
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint32_t m = (uint32_t)c->m;
+  RES(c, c->trec, std::max<size_t>(m, 1) * recsize(c->tgt_type));
+  RES(c, c->trec_tmp, std::max<size_t>(m, 1) * recsize(c->tgt_type));
+  { int r = make_tables(c, c->ttb_mem, c->ttb, (uint32_t)c->gp.nblocks); if (r != PT_OK) return r; }
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (c->tgt_type == PT_F32) {
+    const float* x = (const float*)c->t_xyz.p;
+    pt_launch_grid_sort<float, RecF>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecF*)c->trec.p, (RecF*)c->trec_tmp.p, nullptr, c->ttb, c->stream);
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecF*)c->trec.p, m, k, bound2_dev, idx_dev, d2_dev, c->stream);
+  } else {
+    const double* x = (const double*)c->t_xyz.p;
+    pt_launch_grid_sort<double, RecD>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecD*)c->trec.p, (RecD*)c->trec_tmp.p, nullptr, c->ttb, c->stream);
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecD*)c->trec.p, m, k, bound2_dev, idx_dev, d2_dev, c->stream);
+  }
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  HIPCHK(c, hipGetLastError());
+  c->st.n_target = m;
+  c->st.k = k;
+  const uint64_t s = tsize(c->src_type) * 3;
+  c->st.bytes_alg_query = c->n * s + (uint64_t)m * s + (uint64_t)m * k * 16 + (uint64_t)m * (4 * (uint64_t)k + 24);
+  if (c->sync) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float a = 0, b = 0;
+    HIPCHK(c, hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+    HIPCHK(c, hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+    c->st.ms_sort_targets = a;
+    c->st.ms_query = b;
+  }
+  return PT_OK;
+}
+
+int load_targets(pt_ctx* c, const void* xyz, int xyz_type, uint64_t m, int on_device) {
+  if (xyz_type != PT_F32 && xyz_type != PT_F64) return fail(c, PT_ERR_UNSUPPORTED, "xyz_type %d not supported yet (f32 and f64 are)", xyz_type);
+  if (m && !xyz) return fail(c, PT_ERR_ARG, "target xyz is null");
+  { int r = check_n(c, m, "m"); if (r) return r; }
+  RES(c, c->t_xyz, std::max<uint64_t>(m, 1) * 3 * tsize(xyz_type));
+  { int r = copy_in(c, c->t_xyz.p, xyz, m * 3 * tsize(xyz_type), on_device); if (r) return r; }
+  c->tgt_type = xyz_type;
+  c->m = m;
+  c->t_has_gidx = false;
+  return PT_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int pt_ctx_create(pt_ctx** out, const int* device_ids, int n_devices) {
+  if (!out) return PT_ERR_ARG;
+  *out = nullptr;
+  if (n_devices != 1 && !(n_devices == 0 && !device_ids)) return PT_ERR_ARG;   // one process (context) per GPU
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PT_ERR_HIP;
+  const int dev = device_ids ? device_ids[0] : 0;
+  if (dev < 0 || dev >= count) return PT_ERR_ARG;
+  if (hipSetDevice(dev) != hipSuccess) return PT_ERR_HIP;
+  pt_ctx* c = new pt_ctx();
+  c->device = dev;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERR_HIP; }
+  c->stream = c->own_stream;
+  for (auto& e : c->ev)
+    if (hipEventCreate(&e) != hipSuccess) { delete c; return PT_ERR_HIP; }
+  if (hipHostMalloc((void**)&c->h_bbox, 8 * sizeof(uint64_t)) != hipSuccess || hipHostMalloc((void**)&c->h_counter, 64) != hipSuccess) {
+    delete c;
+    return PT_ERR_HIP;
+  }
+  if (reserve(c, c->bbox6, 64) != PT_OK || reserve(c, c->counter, 64) != PT_OK) { delete c; return PT_ERR_NOMEM; }
+  *out = c;
+  return PT_OK;
+}
+
+void pt_ctx_destroy(pt_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  DevBuf* all[] = {&c->in_xyz, &c->in_gidx, &c->attr, &c->rec, &c->rec_tmp, &c->cell_start, &c->stb_mem, &c->t_xyz, &c->t_gidx, &c->trec,
+                   &c->trec_tmp, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds};
+  for (DevBuf* b : all) release(c, *b);
+  if (c->h_bbox) (void)hipHostFree(c->h_bbox);
+  if (c->h_counter) (void)hipHostFree(c->h_counter);
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int pt_set_stream(pt_ctx* c, void* hip_stream) {
+  if (!c) return PT_ERR_ARG;
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return PT_OK;
+}
+
+int pt_set_param(pt_ctx* c, const char* name, double value) {
+  if (!c || !name) return PT_ERR_ARG;
+  if (!strcmp(name, "rho")) { if (!(value >= 0.25 && value <= 4096)) return fail(c, PT_ERR_ARG, "rho out of range"); c->rho = value; return PT_OK; }
+  if (!strcmp(name, "sync")) { c->sync = value != 0; return PT_OK; }
+  return fail(c, PT_ERR_ARG, "unknown parameter '%s'", name);
+}
+
+const char* pt_last_error(pt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int pt_stats(pt_ctx* c, pt_stats_t* out) {
+  if (!c || !out) return PT_ERR_ARG;
+  c->st.device_bytes = c->dev_bytes;
+  *out = c->st;
+  return PT_OK;
+}
+
+int pt_synchronize(pt_ctx* c) {
+  if (!c) return PT_ERR_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PT_OK;
+}
+
+uint64_t pt_num_source(pt_ctx* c) { return c ? c->n : 0; }
+uint64_t pt_num_targets(pt_ctx* c) { return c ? c->m : 0; }
+
+// ---- build ----------------------------------------------------------------------------------------
+int pt_build_aos(pt_ctx* c, const pt_point* cloud, uint64_t n) {
+  if (!c) return PT_ERR_ARG;
+  if (n && !cloud) return fail(c, PT_ERR_ARG, "cloud is null");
+  { int r = check_n(c, n, "n"); if (r) return r; }
+  HIPCHK(c, hipSetDevice(c->device));
+  RES(c, c->aos_stage, std::max<uint64_t>(n, 1) * sizeof(pt_point));
+  RES(c, c->in_xyz, std::max<uint64_t>(n, 1) * 3 * sizeof(double));
+  RES(c, c->attr, std::max<uint64_t>(n, 1) * sizeof(Attr));
+  { int r = copy_in(c, c->aos_stage.p, cloud, n * sizeof(pt_point), 0); if (r) return r; }
+  double* x = (double*)c->in_xyz.p;
+  pt_launch_aos_split(c->aos_stage.p, (uint32_t)n, x, x + n, x + 2 * n, (Attr*)c->attr.p, c->stream);
+  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false;
+  return rebuild(c);
+}
+
+int pt_build_soa_indexed(pt_ctx* c, const void* xyz, int xyz_type, const uint32_t* gidx, uint64_t n, int on_device) {
+  if (!c) return PT_ERR_ARG;
+  if (xyz_type != PT_F32 && xyz_type != PT_F64) return fail(c, PT_ERR_UNSUPPORTED, "xyz_type %d not supported yet (f32 and f64 are)", xyz_type);
+  if (n && !xyz) return fail(c, PT_ERR_ARG, "xyz is null");
+  { int r = check_n(c, n, "n"); if (r) return r; }
+  HIPCHK(c, hipSetDevice(c->device));
+  RES(c, c->in_xyz, std::max<uint64_t>(n, 1) * 3 * tsize(xyz_type));
+  { int r = copy_in(c, c->in_xyz.p, xyz, n * 3 * tsize(xyz_type), on_device); if (r) return r; }
+  if (gidx) {
+    RES(c, c->in_gidx, std::max<uint64_t>(n, 1) * sizeof(uint32_t));
+    { int r = copy_in(c, c->in_gidx.p, gidx, n * sizeof(uint32_t), on_device); if (r) return r; }
+  }
+  c->src_type = xyz_type; c->n = n; c->has_gidx = gidx != nullptr; c->built = false;
+  if (!gidx) { c->n_total = n; c->has_attr = false; }
+  return rebuild(c);
+}
+
+int pt_set_attributes(pt_ctx* c, const uint8_t* rgb, const float* nrm, uint64_t n_total, int on_device) {
+  if (!c) return PT_ERR_ARG;
+  { int r = check_n(c, n_total, "n_total"); if (r) return r; }
+  HIPCHK(c, hipSetDevice(c->device));
+  RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
+  const uint8_t* drgb = rgb;
+  const float* dnrm = nrm;
+  if (!on_device) {
+    RES(c, c->misc, std::max<uint64_t>(n_total, 1) * 15);
+    uint8_t* base = (uint8_t*)c->misc.p;
+    if (nrm) { int r = copy_in(c, base, nrm, n_total * 12, 0); if (r) return r; dnrm = (const float*)base; }
+    if (rgb) { int r = copy_in(c, base + n_total * 12, rgb, n_total * 3, 0); if (r) return r; drgb = base + n_total * 12; }
+  }
+  pt_launch_pack_attr(drgb, dnrm, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
+  c->n_total = n_total;
+  c->has_attr = true;
+  return finish(c);
+}
+
+int pt_build_soa(pt_ctx* c, const void* xyz, int xyz_type, const uint8_t* rgb, const float* nrm, uint64_t n, int on_device) {
+  int r = pt_build_soa_indexed(c, xyz, xyz_type, nullptr, n, on_device);
+  if (r != PT_OK) return r;
+  if (rgb || nrm) return pt_set_attributes(c, rgb, nrm, n, on_device);
+  return PT_OK;
+}
+
+int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz_type, int slab_axis, double slab_lo, double slab_hi) {
+  if (!c) return PT_ERR_ARG;
+  if (dist != PT_DIST_UNIFORM) return fail(c, PT_ERR_UNSUPPORTED, "only the uniform generator is implemented");
+  if (xyz_type != PT_F32 && xyz_type != PT_F64) return fail(c, PT_ERR_UNSUPPORTED, "xyz_type %d not supported yet (f32 and f64 are)", xyz_type);
+  if (slab_axis > 2) return fail(c, PT_ERR_ARG, "slab_axis must be < 3");
+  { int r = check_n(c, n_total, "n_total"); if (r) return r; }
+  HIPCHK(c, hipSetDevice(c->device));
+  uint64_t n = n_total;
+  const bool slab = slab_axis >= 0;
+  if (slab) {   // counting pass
+    HIPCHK(c, hipMemsetAsync(c->counter.p, 0, 4, c->stream));
+    pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, nullptr, nullptr, nullptr, nullptr, (uint32_t*)c->counter.p, 0, c->stream);
+    HIPCHK(c, hipMemcpyAsync(c->h_counter, c->counter.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    n = *c->h_counter;
+    RES(c, c->in_gidx, std::max<uint64_t>(n, 1) * sizeof(uint32_t));
+    HIPCHK(c, hipMemsetAsync(c->counter.p, 0, 4, c->stream));
+  }
+  RES(c, c->in_xyz, std::max<uint64_t>(n, 1) * 3 * tsize(xyz_type));
+  uint32_t* g = slab ? (uint32_t*)c->in_gidx.p : nullptr;
+  if (xyz_type == PT_F32) { float* x = (float*)c->in_xyz.p; pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, c->stream); }
+  else { double* x = (double*)c->in_xyz.p; pt_launch_synth_xyz<double>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, c->stream); }
+  RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
+  pt_launch_synth_attr(seed, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
+  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false;
+  return rebuild(c);
+}
+
+int pt_rebuild(pt_ctx* c) {
+  if (!c) return PT_ERR_ARG;
+  return rebuild(c);
+}
+
+// ---- query ----------------------------------------------------------------------------------------
+int pt_targets_synth(pt_ctx* c, uint64_t m_total, uint64_t seed, int dist, int xyz_type, int slab_axis, double slab_lo, double slab_hi) {
+  if (!c) return PT_ERR_ARG;
+  if (dist != PT_DIST_UNIFORM) return fail(c, PT_ERR_UNSUPPORTED, "only the uniform generator is implemented");
+  if (xyz_type != PT_F32 && xyz_type != PT_F64) return fail(c, PT_ERR_UNSUPPORTED, "xyz_type %d not supported yet (f32 and f64 are)", xyz_type);
+  if (slab_axis > 2) return fail(c, PT_ERR_ARG, "slab_axis must be < 3");
+  { int r = check_n(c, m_total, "m_total"); if (r) return r; }
+  HIPCHK(c, hipSetDevice(c->device));
+  uint64_t m = m_total;
+  const bool slab = slab_axis >= 0;
+  if (slab) {
+    HIPCHK(c, hipMemsetAsync(c->counter.p, 0, 4, c->stream));
+    pt_launch_synth_xyz<float>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, nullptr, nullptr, nullptr, nullptr, (uint32_t*)c->counter.p, 0, c->stream);
+    HIPCHK(c, hipMemcpyAsync(c->h_counter, c->counter.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    m = *c->h_counter;
+    HIPCHK(c, hipMemsetAsync(c->counter.p, 0, 4, c->stream));
+  }
+  RES(c, c->t_gidx, std::max<uint64_t>(m, 1) * sizeof(uint32_t));
+  RES(c, c->t_xyz, std::max<uint64_t>(m, 1) * 3 * tsize(xyz_type));
+  uint32_t* g = (uint32_t*)c->t_gidx.p;
+  if (xyz_type == PT_F32) { float* x = (float*)c->t_xyz.p; pt_launch_synth_xyz<float>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, x, x + m, x + 2 * m, g, (uint32_t*)c->counter.p, (uint32_t)m, c->stream); }
+  else { double* x = (double*)c->t_xyz.p; pt_launch_synth_xyz<double>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, x, x + m, x + 2 * m, g, (uint32_t*)c->counter.p, (uint32_t)m, c->stream); }
+  c->tgt_type = xyz_type; c->m = m; c->t_has_gidx = true;
+  return finish(c);
+}
+
+int pt_query_resident(pt_ctx* c, int k, uint32_t* idx_dev, double* d2_dev_or_null) {
+  if (!c) return PT_ERR_ARG;
+  if (c->tgt_type < 0) return fail(c, PT_ERR_STATE, "no resident targets");
+  return query_resident(c, k, nullptr, idx_dev, d2_dev_or_null);
+}
+
+int pt_resident_target_ids(pt_ctx* c, uint32_t* ids_dev) {
+  if (!c || !ids_dev) return PT_ERR_ARG;
+  if (c->tgt_type < 0) return fail(c, PT_ERR_STATE, "no resident targets");
+  if (c->t_has_gidx) HIPCHK(c, hipMemcpyAsync(ids_dev, c->t_gidx.p, c->m * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+  else pt_launch_iota(ids_dev, (uint32_t)c->m, c->stream);
+  return finish(c);
+}
+
+int pt_resident_target_xyz(pt_ctx* c, void* xyz_dev) {
+  if (!c || !xyz_dev) return PT_ERR_ARG;
+  if (c->tgt_type < 0) return fail(c, PT_ERR_STATE, "no resident targets");
+  HIPCHK(c, hipMemcpyAsync(xyz_dev, c->t_xyz.p, c->m * 3 * tsize(c->tgt_type), hipMemcpyDeviceToDevice, c->stream));
+  return finish(c);
+}
+
+int pt_query_soa(pt_ctx* c, const void* xyz, int xyz_type, uint64_t m, int k, int on_device, uint32_t* idx, double* d2_or_null) {
+  if (!c) return PT_ERR_ARG;
+  if (!c->built) return fail(c, PT_ERR_STATE, "query before build");
+  if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k = %d out of range [1, %d]", k, PT_MAX_K);
+  if (m && !idx) return fail(c, PT_ERR_ARG, "idx output is null");
+  { int r = load_targets(c, xyz, xyz_type, m, on_device); if (r) return r; }
+  if (on_device) return query_resident(c, k, nullptr, idx, d2_or_null);
+  RES(c, c->q_idx, std::max<uint64_t>(m, 1) * k * sizeof(uint32_t));
+  if (d2_or_null) RES(c, c->q_d2, std::max<uint64_t>(m, 1) * k * sizeof(double));
+  { int r = query_resident(c, k, nullptr, (uint32_t*)c->q_idx.p, d2_or_null ? (double*)c->q_d2.p : nullptr); if (r) return r; }
+  if (m) {
+    HIPCHK(c, hipMemcpyAsync(idx, c->q_idx.p, m * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (d2_or_null) HIPCHK(c, hipMemcpyAsync(d2_or_null, c->q_d2.p, m * k * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return PT_OK;
+}
+
+int pt_query_aos(pt_ctx* c, const pt_point* targets, uint64_t m, int k, uint32_t* idx, double* d2_or_null) {
+  if (!c) return PT_ERR_ARG;
+  if (!c->built) return fail(c, PT_ERR_STATE, "query before build");
+  if (m && (!targets || !idx)) return fail(c, PT_ERR_ARG, "null argument");
+  { int r = check_n(c, m, "m"); if (r) return r; }
+  HIPCHK(c, hipSetDevice(c->device));
+  RES(c, c->aos_stage, std::max<uint64_t>(m, 1) * sizeof(pt_point));
+  RES(c, c->t_xyz, std::max<uint64_t>(m, 1) * 3 * sizeof(double));
+  { int r = copy_in(c, c->aos_stage.p, targets, m * sizeof(pt_point), 0); if (r) return r; }
+  double* x = (double*)c->t_xyz.p;
+  pt_launch_aos_split(c->aos_stage.p, (uint32_t)m, x, x + m, x + 2 * m, nullptr, c->stream);
+  c->tgt_type = PT_F64; c->m = m; c->t_has_gidx = false;
+  RES(c, c->q_idx, std::max<uint64_t>(m, 1) * k * sizeof(uint32_t));
+  if (d2_or_null) RES(c, c->q_d2, std::max<uint64_t>(m, 1) * k * sizeof(double));
+  { int r = query_resident(c, k, nullptr, (uint32_t*)c->q_idx.p, d2_or_null ? (double*)c->q_d2.p : nullptr); if (r) return r; }
+  if (m) {
+    HIPCHK(c, hipMemcpyAsync(idx, c->q_idx.p, m * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (d2_or_null) HIPCHK(c, hipMemcpyAsync(d2_or_null, c->q_d2.p, m * k * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return PT_OK;
+}
+
+int pt_query_bounded_dev(pt_ctx* c, const void* xyz_dev, int xyz_type, const double* bound2_dev, uint64_t m, int k, uint32_t* idx_dev,
+                         double* d2_dev) {
+  if (!c) return PT_ERR_ARG;
+  { int r = load_targets(c, xyz_dev, xyz_type, m, 1); if (r) return r; }
+  return query_resident(c, k, bound2_dev, idx_dev, d2_dev);
+}
+
+// ---- blend / PCA -----------------------------------------------------------------------------------
+int pt_blend_dev(pt_ctx* c, const uint32_t* idx_dev, const double* d2_dev_or_null, uint64_t m, int k, int mode, float* rgb_out_dev,
+                 float* nrm_out_dev) {
+  if (!c) return PT_ERR_ARG;
+  if (!c->has_attr) return fail(c, PT_ERR_STATE, "no attribute table resident");
+  if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k out of range");
+  if (mode != PT_BLEND_MEAN && mode != PT_BLEND_INV_D2) return fail(c, PT_ERR_ARG, "unknown blend mode %d", mode);
+  if (mode == PT_BLEND_INV_D2 && !d2_dev_or_null) return fail(c, PT_ERR_ARG, "inverse-d2 blend needs d2");
+  if (m && !idx_dev) return fail(c, PT_ERR_ARG, "idx is null");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  pt_launch_blend(idx_dev, d2_dev_or_null, (uint32_t)m, k, mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, rgb_out_dev, nrm_out_dev, c->stream);
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  HIPCHK(c, hipGetLastError());
+  if (c->sync) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->st.ms_blend = ms;
+  }
+  return PT_OK;
+}
+
+int pt_blend(pt_ctx* c, const uint32_t* idx, const double* d2_or_null, uint64_t m, int k, int mode, float* rgb_out, float* nrm_out) {
+  if (!c) return PT_ERR_ARG;
+  if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k out of range");
+  if (m && !idx) return fail(c, PT_ERR_ARG, "idx is null");
+  HIPCHK(c, hipSetDevice(c->device));
+  RES(c, c->q_idx, std::max<uint64_t>(m, 1) * k * sizeof(uint32_t));
+  RES(c, c->q_d2, std::max<uint64_t>(m, 1) * k * sizeof(double));
+  RES(c, c->b_rgb, std::max<uint64_t>(m, 1) * 12);
+  RES(c, c->b_nrm, std::max<uint64_t>(m, 1) * 12);
+  { int r = copy_in(c, c->q_idx.p, idx, m * k * sizeof(uint32_t), 0); if (r) return r; }
+  if (d2_or_null) { int r = copy_in(c, c->q_d2.p, d2_or_null, m * k * sizeof(double), 0); if (r) return r; }
+  const int sync_save = c->sync;
+  c->sync = 1;
+  int r = pt_blend_dev(c, (const uint32_t*)c->q_idx.p, d2_or_null ? (const double*)c->q_d2.p : nullptr, m, k, mode, (float*)c->b_rgb.p, (float*)c->b_nrm.p);
+  c->sync = sync_save;
+  if (r != PT_OK) return r;
+  if (m) {
+    if (rgb_out) HIPCHK(c, hipMemcpy(rgb_out, c->b_rgb.p, m * 12, hipMemcpyDeviceToHost));
+    if (nrm_out) HIPCHK(c, hipMemcpy(nrm_out, c->b_nrm.p, m * 12, hipMemcpyDeviceToHost));
+  }
+  return PT_OK;
+}
+
+int pt_pca_normals_dev(pt_ctx* c, const uint32_t* idx_dev, uint64_t m, int k, float* nrm_out_dev) {
+  if (!c) return PT_ERR_ARG;
+  if (c->src_type < 0) return fail(c, PT_ERR_STATE, "no source cloud resident");
+  if (c->has_gidx) return fail(c, PT_ERR_UNSUPPORTED, "PCA normals need the whole cloud resident (not a slab)");
+  if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k out of range");
+  if (m && (!idx_dev || !nrm_out_dev)) return fail(c, PT_ERR_ARG, "null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  const Attr* at = c->has_attr ? (const Attr*)c->attr.p : nullptr;
+  if (c->src_type == PT_F32) { const float* x = (const float*)c->in_xyz.p; pt_launch_pca<float>(idx_dev, (uint32_t)m, k, x, x + c->n, x + 2 * c->n, (uint32_t)c->n, at, nrm_out_dev, c->stream); }
+  else { const double* x = (const double*)c->in_xyz.p; pt_launch_pca<double>(idx_dev, (uint32_t)m, k, x, x + c->n, x + 2 * c->n, (uint32_t)c->n, at, nrm_out_dev, c->stream); }
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  HIPCHK(c, hipGetLastError());
+  if (c->sync) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->st.ms_pca = ms;
+  }
+  return PT_OK;
+}
+
+int pt_pca_normals(pt_ctx* c, const uint32_t* idx, uint64_t m, int k, float* nrm_out) {
+  if (!c) return PT_ERR_ARG;
+  if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k out of range");
+  if (m && (!idx || !nrm_out)) return fail(c, PT_ERR_ARG, "null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  RES(c, c->q_idx, std::max<uint64_t>(m, 1) * k * sizeof(uint32_t));
+  RES(c, c->b_nrm, std::max<uint64_t>(m, 1) * 12);
+  { int r = copy_in(c, c->q_idx.p, idx, m * k * sizeof(uint32_t), 0); if (r) return r; }
+  const int sync_save = c->sync;
+  c->sync = 1;
+  int r = pt_pca_normals_dev(c, (const uint32_t*)c->q_idx.p, m, k, (float*)c->b_nrm.p);
+  c->sync = sync_save;
+  if (r != PT_OK) return r;
+  if (m) HIPCHK(c, hipMemcpy(nrm_out, c->b_nrm.p, m * 12, hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+// ---- multi-GPU helpers -------------------------------------------------------------------------------
+int pt_merge_candidates_dev(pt_ctx* c, const uint32_t* idx_lists_dev, const double* d2_lists_dev, int g, uint64_t m, int k,
+                            uint32_t* idx_out_dev, double* d2_out_dev) {
+  if (!c) return PT_ERR_ARG;
+  if (g < 1 || g > 64 || k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "g or k out of range");
+  if (m && (!idx_lists_dev || !d2_lists_dev || !idx_out_dev || !d2_out_dev)) return fail(c, PT_ERR_ARG, "null argument");
+  { int r = check_n(c, m, "m"); if (r) return r; }
+  HIPCHK(c, hipSetDevice(c->device));
+  pt_launch_merge(idx_lists_dev, d2_lists_dev, g, (uint32_t)m, k, idx_out_dev, d2_out_dev, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return finish(c);
+}
+
+int pt_slab_need_dev(pt_ctx* c, const void* tgt_xyz_dev, int xyz_type, const double* d2_dev, uint64_t m, int k, int slab_axis,
+                     const double* slab_bounds, int g, int my_slab, uint8_t* need_dev) {
+  if (!c) return PT_ERR_ARG;
+  if (xyz_type != PT_F32 && xyz_type != PT_F64) return fail(c, PT_ERR_UNSUPPORTED, "xyz_type %d not supported yet", xyz_type);
+  if (g < 1 || g > 64 || k < 1 || k > PT_MAX_K || slab_axis < 0 || slab_axis > 2 || my_slab < 0 || my_slab >= g) return fail(c, PT_ERR_ARG, "argument out of range");
+  if (m && (!tgt_xyz_dev || !d2_dev || !need_dev || !slab_bounds)) return fail(c, PT_ERR_ARG, "null argument");
+  { int r = check_n(c, m, "m"); if (r) return r; }
+  HIPCHK(c, hipSetDevice(c->device));
+  RES(c, c->bounds, 65 * sizeof(double));
+  HIPCHK(c, hipMemcpyAsync(c->bounds.p, slab_bounds, (size_t)(g + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (xyz_type == PT_F32) { const float* x = (const float*)tgt_xyz_dev; pt_launch_slab_need<float>(x, x + m, x + 2 * m, d2_dev, (uint32_t)m, k, slab_axis, (const double*)c->bounds.p, g, my_slab, need_dev, c->stream); }
+  else { const double* x = (const double*)tgt_xyz_dev; pt_launch_slab_need<double>(x, x + m, x + 2 * m, d2_dev, (uint32_t)m, k, slab_axis, (const double*)c->bounds.p, g, my_slab, need_dev, c->stream); }
+  HIPCHK(c, hipGetLastError());
+  return finish(c);
+}
+
+}  // extern "C"

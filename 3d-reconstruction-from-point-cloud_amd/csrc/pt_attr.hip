@@ -1,0 +1,236 @@
+// pt_attr.hip -- everything around the search that touches attributes or raw input, for gfx950 (MI355X):
+//   * the index-addressable synthetic generator of SURVEY.md Appendix C (bit-identical to the CPU checker under oracle/
+//     for xyz and colour: integer hashing + one exact int->float conversion);
+//   * the AoS -> planar split of the reference's 80-byte Point records (reference src/Point.h:1-6);
+//   * attribute gather + blend.  The reference's only blend arithmetic is the barycentric colour mix of its
+//     rasteriser (reference src/pointsTransfer.cpp:95-97: weights * colours summed as double products);
+//     the per-vertex k-neighbour blend keeps that shape (out = sum_j w_j * a_j) with build-defined weights;
+//   * PCA normals from the neighbours (BASELINE config 3; no reference counterpart).
+#include "pt_internal.h"
+
+namespace {
+
+constexpr int WG = 256;
+
+__host__ __device__ inline uint64_t splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline uint64_t stream_key(uint64_t seed, uint64_t stream) { return splitmix64(seed ^ (stream << 56)); }
+__device__ inline float u24(uint64_t h) { return (float)(uint32_t)(h >> 40) * (1.0f / 16777216.0f); }
+
+template <class T>
+__global__ __launch_bounds__(WG) void synth_xyz_kernel(uint64_t key, uint32_t n_total, int axis, double lo, double hi, T* __restrict__ x,
+                                                       T* __restrict__ y, T* __restrict__ z, uint32_t* __restrict__ gidx, uint32_t* counter,
+                                                       uint32_t capacity) {
+  const uint32_t i = blockIdx.x * WG + threadIdx.x;
+  if (i >= n_total) return;
+  const float px = u24(splitmix64(key + 4ull * i + 0));
+  const float py = u24(splitmix64(key + 4ull * i + 1));
+  const float pz = u24(splitmix64(key + 4ull * i + 2));
+  uint32_t pos = i;
+  if (axis >= 0) {
+    const double c = (double)(axis == 0 ? px : (axis == 1 ? py : pz));
+    if (!(c >= lo && c < hi)) return;
+    pos = atomicAdd(counter, 1u);      // hipcc folds this into one atomic per wave
+    if (!x || pos >= capacity) return;   // counting pass, or overflow (host checks the counter)
+  }
+  x[pos] = (T)px; y[pos] = (T)py; z[pos] = (T)pz;
+  if (gidx) gidx[pos] = i;
+}
+
+__global__ __launch_bounds__(WG) void synth_attr_kernel(uint64_t key_rgb, uint64_t key_nrm, uint32_t n_total, Attr* __restrict__ attr) {
+#pragma clang fp contract(off)
+  const uint32_t i = blockIdx.x * WG + threadIdx.x;
+  if (i >= n_total) return;
+  Attr a;
+  a.rgba = (uint32_t)(splitmix64(key_rgb + 4ull * i) & 0xFFFFFFu);
+  float nx = 2.0f * u24(splitmix64(key_nrm + 4ull * i + 0)) - 1.0f;
+  float ny = 2.0f * u24(splitmix64(key_nrm + 4ull * i + 1)) - 1.0f;
+  float nz = 2.0f * u24(splitmix64(key_nrm + 4ull * i + 2)) - 1.0f;
+  const float len = sqrtf((nx * nx + ny * ny) + nz * nz);
+  if (len < 1e-12f) { nx = 0.f; ny = 0.f; nz = 1.f; }
+  else { nx = nx / len; ny = ny / len; nz = nz / len; }
+  a.nx = nx; a.ny = ny; a.nz = nz;
+  attr[i] = a;
+}
+
+// reference Point: ver f64x3 @0, normal f64x3 @24, color i32x3 @48, U @64, V @72 (80 B)
+__global__ __launch_bounds__(WG) void aos_split_kernel(const unsigned char* __restrict__ aos, uint32_t n, double* __restrict__ x,
+                                                       double* __restrict__ y, double* __restrict__ z, Attr* __restrict__ attr) {
+  const uint32_t i = blockIdx.x * WG + threadIdx.x;
+  if (i >= n) return;
+  const double* d = (const double*)(aos + (size_t)i * 80);
+  const int* col = (const int*)(aos + (size_t)i * 80 + 48);
+  x[i] = d[0]; y[i] = d[1]; z[i] = d[2];
+  if (attr) {
+    Attr a;
+    const uint32_t r = (uint32_t)min(max(col[0], 0), 255), g = (uint32_t)min(max(col[1], 0), 255), b = (uint32_t)min(max(col[2], 0), 255);
+    a.rgba = r | (g << 8) | (b << 16);
+    a.nx = (float)d[3]; a.ny = (float)d[4]; a.nz = (float)d[5];
+    attr[i] = a;
+  }
+}
+
+__global__ __launch_bounds__(WG) void pack_attr_kernel(const uint8_t* __restrict__ rgb, const float* __restrict__ nrm, uint32_t n,
+                                                       Attr* __restrict__ attr) {
+  const uint32_t i = blockIdx.x * WG + threadIdx.x;
+  if (i >= n) return;
+  Attr a;
+  a.rgba = rgb ? ((uint32_t)rgb[3 * (size_t)i] | ((uint32_t)rgb[3 * (size_t)i + 1] << 8) | ((uint32_t)rgb[3 * (size_t)i + 2] << 16)) : 0u;
+  a.nx = nrm ? nrm[3 * (size_t)i] : 0.f;
+  a.ny = nrm ? nrm[3 * (size_t)i + 1] : 0.f;
+  a.nz = nrm ? nrm[3 * (size_t)i + 2] : 0.f;
+  attr[i] = a;
+}
+
+// one thread per target: gather the k neighbours' 16-B attribute records and blend them
+__global__ __launch_bounds__(WG) void blend_kernel(const uint32_t* __restrict__ idx, const double* __restrict__ d2, uint32_t m, int k, int mode,
+                                                   const Attr* __restrict__ attr, uint32_t n_attr, float* __restrict__ rgb_out,
+                                                   float* __restrict__ nrm_out) {
+  const uint32_t t = blockIdx.x * WG + threadIdx.x;
+  if (t >= m) return;
+  double wsum = 0.0, c[3] = {0, 0, 0}, nn[3] = {0, 0, 0};
+  for (int j = 0; j < k; ++j) {
+    const uint32_t id = idx[(size_t)t * k + j];
+    if (id == PT_NOIDX_U || id >= n_attr) continue;
+    const double w = (mode == 1) ? 1.0 / (d2[(size_t)t * k + j] + 1e-12) : 1.0;
+    const Attr a = attr[id];
+    wsum += w;
+    c[0] += w * (double)(a.rgba & 0xFFu); c[1] += w * (double)((a.rgba >> 8) & 0xFFu); c[2] += w * (double)((a.rgba >> 16) & 0xFFu);
+    nn[0] += w * (double)a.nx; nn[1] += w * (double)a.ny; nn[2] += w * (double)a.nz;
+  }
+  if (wsum > 0.0) {
+    const double iw = 1.0 / wsum;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { c[a] *= iw; nn[a] *= iw; }
+    const double len = sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+    if (len >= 1e-12) { nn[0] /= len; nn[1] /= len; nn[2] /= len; }
+  }
+  if (rgb_out) { rgb_out[3 * (size_t)t] = (float)c[0]; rgb_out[3 * (size_t)t + 1] = (float)c[1]; rgb_out[3 * (size_t)t + 2] = (float)c[2]; }
+  if (nrm_out) { nrm_out[3 * (size_t)t] = (float)nn[0]; nrm_out[3 * (size_t)t + 1] = (float)nn[1]; nrm_out[3 * (size_t)t + 2] = (float)nn[2]; }
+}
+
+// cyclic Jacobi on a symmetric 3x3 (fp64), same sweep order as the oracle
+__device__ inline void jacobi3(double (&a)[3][3], double (&v)[3][3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+    if (off < 1e-300) break;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 3; ++q) {
+        if (fabs(a[p][q]) < 1e-300) continue;
+        const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { const double arp = a[r][p], arq = a[r][q]; a[r][p] = cs * arp - sn * arq; a[r][q] = sn * arp + cs * arq; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { const double apr = a[p][r], aqr = a[q][r]; a[p][r] = cs * apr - sn * aqr; a[q][r] = sn * apr + cs * aqr; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { const double vrp = v[r][p], vrq = v[r][q]; v[r][p] = cs * vrp - sn * vrq; v[r][q] = sn * vrp + cs * vrq; }
+      }
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(WG) void pca_kernel(const uint32_t* __restrict__ idx, uint32_t m, int k, const T* __restrict__ x,
+                                                 const T* __restrict__ y, const T* __restrict__ z, uint32_t n, const Attr* __restrict__ attr,
+                                                 float* __restrict__ nrm_out) {
+  const uint32_t t = blockIdx.x * WG + threadIdx.x;
+  if (t >= m) return;
+  double mu[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+  int ke = 0;
+  for (int j = 0; j < k; ++j) {
+    const uint32_t id = idx[(size_t)t * k + j];
+    if (id == PT_NOIDX_U || id >= n) continue;
+    mu[0] += (double)x[id]; mu[1] += (double)y[id]; mu[2] += (double)z[id];
+    ++ke;
+    if (attr) { const Attr a = attr[id]; mn[0] += (double)a.nx; mn[1] += (double)a.ny; mn[2] += (double)a.nz; }
+  }
+  float* o = nrm_out + 3 * (size_t)t;
+  if (ke < 3) { o[0] = 0.f; o[1] = 0.f; o[2] = 1.f; return; }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) mu[a] /= (double)ke;
+  double cv[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int j = 0; j < k; ++j) {
+    const uint32_t id = idx[(size_t)t * k + j];
+    if (id == PT_NOIDX_U || id >= n) continue;
+    const double d[3] = {(double)x[id] - mu[0], (double)y[id] - mu[1], (double)z[id] - mu[2]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) cv[a][b] += d[a] * d[b];
+  }
+  double v[3][3];
+  jacobi3(cv, v);
+  const double e0 = cv[0][0], e1 = cv[1][1], e2 = cv[2][2];
+  double nn[3];
+  if (e0 <= e1 && e0 <= e2) { nn[0] = v[0][0]; nn[1] = v[1][0]; nn[2] = v[2][0]; }
+  else if (e1 <= e2) { nn[0] = v[0][1]; nn[1] = v[1][1]; nn[2] = v[2][1]; }
+  else { nn[0] = v[0][2]; nn[1] = v[1][2]; nn[2] = v[2][2]; }
+  const double len = sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+  const double ref = attr ? (nn[0] * mn[0] + nn[1] * mn[1] + nn[2] * mn[2]) : nn[2];
+  const double sgn = (ref < 0 ? -1.0 : 1.0) / len;
+  o[0] = (float)(nn[0] * sgn); o[1] = (float)(nn[1] * sgn); o[2] = (float)(nn[2] * sgn);
+}
+
+__global__ __launch_bounds__(WG) void iota_kernel(uint32_t* p, uint32_t n) {
+  const uint32_t i = blockIdx.x * WG + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+inline dim3 grid_for(uint32_t n) { return dim3((n + WG - 1) / WG); }
+
+}  // namespace
+
+template <class T>
+void pt_launch_synth_xyz(uint64_t seed, uint64_t stream, uint32_t n_total, int axis, double lo, double hi, T* x, T* y, T* z, uint32_t* gidx,
+                         uint32_t* counter, uint32_t capacity, hipStream_t s) {
+  if (!n_total) return;
+  hipLaunchKernelGGL(synth_xyz_kernel<T>, grid_for(n_total), dim3(WG), 0, s, stream_key(seed, stream), n_total, axis, lo, hi, x, y, z, gidx,
+                     counter, capacity);
+}
+template void pt_launch_synth_xyz<float>(uint64_t, uint64_t, uint32_t, int, double, double, float*, float*, float*, uint32_t*, uint32_t*, uint32_t,
+                                         hipStream_t);
+template void pt_launch_synth_xyz<double>(uint64_t, uint64_t, uint32_t, int, double, double, double*, double*, double*, uint32_t*, uint32_t*,
+                                          uint32_t, hipStream_t);
+
+void pt_launch_synth_attr(uint64_t seed, uint32_t n_total, Attr* attr, hipStream_t s) {
+  if (!n_total) return;
+  hipLaunchKernelGGL(synth_attr_kernel, grid_for(n_total), dim3(WG), 0, s, stream_key(seed, 2), stream_key(seed, 3), n_total, attr);
+}
+void pt_launch_aos_split(const void* aos, uint32_t n, double* x, double* y, double* z, Attr* attr, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(aos_split_kernel, grid_for(n), dim3(WG), 0, s, (const unsigned char*)aos, n, x, y, z, attr);
+}
+void pt_launch_pack_attr(const uint8_t* rgb, const float* nrm, uint32_t n, Attr* attr, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(pack_attr_kernel, grid_for(n), dim3(WG), 0, s, rgb, nrm, n, attr);
+}
+void pt_launch_blend(const uint32_t* idx, const double* d2, uint32_t m, int k, int mode, const Attr* attr, uint32_t n_attr, float* rgb_out,
+                     float* nrm_out, hipStream_t s) {
+  if (!m) return;
+  hipLaunchKernelGGL(blend_kernel, grid_for(m), dim3(WG), 0, s, idx, d2, m, k, mode, attr, n_attr, rgb_out, nrm_out);
+}
+template <class T>
+void pt_launch_pca(const uint32_t* idx, uint32_t m, int k, const T* x, const T* y, const T* z, uint32_t n, const Attr* attr, float* nrm_out,
+                   hipStream_t s) {
+  if (!m) return;
+  hipLaunchKernelGGL(pca_kernel<T>, grid_for(m), dim3(WG), 0, s, idx, m, k, x, y, z, n, attr, nrm_out);
+}
+template void pt_launch_pca<float>(const uint32_t*, uint32_t, int, const float*, const float*, const float*, uint32_t, const Attr*, float*,
+                                   hipStream_t);
+template void pt_launch_pca<double>(const uint32_t*, uint32_t, int, const double*, const double*, const double*, uint32_t, const Attr*, float*,
+                                    hipStream_t);
+void pt_launch_iota(uint32_t* p, uint32_t n, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(WG), 0, s, p, n);
+}

@@ -1,0 +1,66 @@
+// pt_common.h -- types shared by the gfx950 kernels and the C-ABI glue (libpt_hip.so).
+//
+// Data layout in HBM:
+//   input cloud      planar xyz  x[n] y[n] z[n]      (f32, or f64 for reference AoS input)
+//   attribute table  16 B / point {rgba8, nx, ny, nz} indexed by ORIGINAL index (one gather / neighbour)
+//   sorted records   16 B {x,y,z,id} (f32) or 32 B (f64): one dwordx4 / 2x dwordx4 load per lane
+//   cell_start       u32[ncells+1]
+//   cell key         = macro (row-major over 64^3-cell macro blocks) << 18
+//                    | Morton3(block within macro, 3 bits / axis)     <<  9
+//                    | row-major cell within the 8x8x8 block (lz<<6 | ly<<3 | lx)
+//                    Morton order keeps spatially close 8^3-cell blocks close in HBM / L2; row-major
+//                    inside a block keeps a run of x-adjacent cells one contiguous 128-B-granular
+//                    range, which is what the query's 8-lane groups load coalesced.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PT_NOIDX_U 0xFFFFFFFFu
+#define PT_BLOCK_CELLS 512          // 8 x 8 x 8 cells per block
+#define PT_MACRO_BLOCKS 512         // 8 x 8 x 8 blocks per macro block
+#define PT_MAXBINS 1024             // LDS histogram bins per partition pass (macro blocks, or blocks when <= 1024)
+#define PT_CELL_EPS 1e-9            // slack (in cell units) on every cell-box bound: cell membership is
+                                    // computed in fp64 with ~1e-12 cell units of rounding at most
+
+struct RecF { float x, y, z; uint32_t id; };                     // 16 B
+struct RecD { double x, y, z; uint32_t id; uint32_t pad; };      // 32 B
+struct Attr { uint32_t rgba; float nx, ny, nz; };                // 16 B
+
+struct GridParams {
+  double bbmin[3];
+  double inv_h, h;
+  int dim[3];        // occupied cells per axis (points are clamped into [0, dim))
+  int mdim[3];       // macro blocks (64 cells) per axis = ceil(dim / 64)
+  int nblocks;       // mdim[0]*mdim[1]*mdim[2]*512   (padded)
+};
+
+// ---- Morton code of 3-bit block coordinates inside a macro block ----------------------------
+__host__ __device__ inline uint32_t pt_spread3(uint32_t v) {   // 3 bits -> every third bit
+  return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4);
+}
+__host__ __device__ inline uint32_t pt_morton9(uint32_t bx, uint32_t by, uint32_t bz) {
+  return pt_spread3(bx) | (pt_spread3(by) << 1) | (pt_spread3(bz) << 2);
+}
+// dense block id of the block holding cell (cx,cy,cz)
+__host__ __device__ inline uint32_t pt_block_id(const int* mdim, int cx, int cy, int cz) {
+  const uint32_t macro = ((uint32_t)(cz >> 6) * (uint32_t)mdim[1] + (uint32_t)(cy >> 6)) * (uint32_t)mdim[0] + (uint32_t)(cx >> 6);
+  return (macro << 9) | pt_morton9((uint32_t)(cx >> 3) & 7u, (uint32_t)(cy >> 3) & 7u, (uint32_t)(cz >> 3) & 7u);
+}
+__host__ __device__ inline uint32_t pt_local_cell(int cx, int cy, int cz) {
+  return (uint32_t)(((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7));
+}
+
+#ifdef __HIPCC__
+// cell coordinate along one axis: clamp(floor((p - bbmin) * inv_h), 0, dim-1), all in fp64
+__device__ inline int pt_cell_axis(double p, double bbmin, double inv_h, int dim) {
+  double u = (p - bbmin) * inv_h;
+  u = fmin(fmax(u, 0.0), (double)(dim - 1));
+  return (int)u;   // u >= 0: truncation == floor
+}
+template <class Rec>
+__device__ inline void pt_cell_of(const GridParams& gp, const Rec& r, int& cx, int& cy, int& cz) {
+  cx = pt_cell_axis((double)r.x, gp.bbmin[0], gp.inv_h, gp.dim[0]);
+  cy = pt_cell_axis((double)r.y, gp.bbmin[1], gp.inv_h, gp.dim[1]);
+  cz = pt_cell_axis((double)r.z, gp.bbmin[2], gp.inv_h, gp.dim[2]);
+}
+#endif

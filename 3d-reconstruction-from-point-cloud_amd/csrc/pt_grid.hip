@@ -1,0 +1,442 @@
+// pt_grid.hip -- on-device spatial grid build for gfx950 (MI355X).
+//
+// Replaces the reference's kd-tree construction `Tree tree(points.begin(), points.end())`
+// (reference src/pointsTransfer.cpp:259; CGAL Kd_tree, lazily built on the first query) with a
+// hand-written MSD radix partition of the points by grid-cell key (pt_common.h):
+//
+//   pass 1   partition by macro block (<= 1024 bins)          read planar xyz, write 16/32-B records
+//   pass 2   partition every macro segment by Morton block id  (512 bins)   records -> records
+//   finalize one workgroup per 8x8x8-cell block: LDS counting sort by local cell, emits cell_start
+//
+// The key is a pure function of xyz, so no key array is ever stored or moved: every pass recomputes the
+// digit it needs from the coordinates.  Order inside a cell is irrelevant (the query imposes the total
+// order (d2, original index) itself), so no pass needs to be stable: ranks inside a tile come from LDS
+// atomics and bin space is reserved with one global atomic per (tile, non-empty bin).  Records are regrouped
+// in LDS before they are written, so every bin's share of a tile leaves the CU as one contiguous run.
+//
+// All of this is HBM-bound byte shuffling: no MFMA, wave64 everywhere, 256-thread workgroups.
+#include "pt_internal.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace {
+
+constexpr int WG = 256;
+
+template <class T> struct RecOf;
+template <> struct RecOf<float> { using type = RecF; };
+template <> struct RecOf<double> { using type = RecD; };
+
+template <class T>
+struct PlanarLoader {
+  using Rec = typename RecOf<T>::type;
+  const T *x, *y, *z;
+  const uint32_t* gidx;
+  __device__ Rec load(uint32_t i) const {
+    Rec r;
+    r.x = x[i]; r.y = y[i]; r.z = z[i];
+    r.id = gidx ? gidx[i] : i;
+    return r;
+  }
+};
+template <class R>
+struct RecLoader {
+  using Rec = R;
+  const R* p;
+  __device__ Rec load(uint32_t i) const { return p[i]; }
+};
+
+struct BinSpec {
+  int mode;    // 0: local bin = blk >> shift, global bin = local      (pass 1)
+               // 1: local bin = blk & mask,   global bin = blk         (pass 2; seg = blk >> shift)
+  int shift;
+  int nbins;   // local bins (<= PT_MAXBINS)
+};
+__device__ inline uint32_t local_bin(const BinSpec& b, uint32_t blk) {
+  return b.mode == 0 ? (blk >> b.shift) : (blk & ((1u << b.shift) - 1u));
+}
+__device__ inline uint32_t global_bin(const BinSpec& b, uint32_t seg, uint32_t local) {
+  return b.mode == 0 ? local : ((seg << b.shift) + local);
+}
+template <class Rec>
+__device__ inline uint32_t block_of_rec(const GridParams& gp, const Rec& r) {
+  int cx, cy, cz;
+  pt_cell_of(gp, r, cx, cy, cz);
+  return pt_block_id(gp.mdim, cx, cy, cz);
+}
+
+// tile -> (segment, [s,e)).  tile_first is the exclusive scan of tiles per segment (nseg+1 entries).
+__device__ inline bool tile_range(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ tile_first, int nseg,
+                                  uint32_t tile, uint32_t tile_pts, uint32_t& seg, uint32_t& s, uint32_t& e) {
+  if (tile >= tile_first[nseg]) return false;
+  int lo = 0, hi = nseg;               // invariant: tile_first[lo] <= tile < tile_first[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_first[mid] <= tile) lo = mid; else hi = mid;
+  }
+  seg = (uint32_t)lo;
+  s = seg_start[lo] + (tile - tile_first[lo]) * tile_pts;
+  const uint32_t send = seg_start[lo + 1];
+  e = (send - s > tile_pts) ? s + tile_pts : send;
+  return true;
+}
+
+__device__ inline uint32_t wave_incl_scan(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+// exclusive scan of one value per thread over a 256-thread workgroup; wsum: LDS scratch of 4 words
+__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* wsum, uint32_t& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t incl = wave_incl_scan(v);
+  __syncthreads();
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  uint32_t off = 0;
+  total = 0;
+#pragma unroll
+  for (int i = 0; i < WG / 64; ++i) {
+    const uint32_t ws = wsum[i];
+    if (i < w) off += ws;
+    total += ws;
+  }
+  return off + incl - v;
+}
+
+// ---- bounding box ------------------------------------------------------------------------------
+__device__ inline uint64_t enc_f64(double d) {
+  const uint64_t b = (uint64_t)__double_as_longlong(d);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+template <class T>
+__global__ __launch_bounds__(WG) void bbox_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, uint32_t n,
+                                                  uint64_t* out6) {
+  double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) {
+    const double v[3] = {(double)x[i], (double)y[i], (double)z[i]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = fmin(mn[a], v[a]); mx[a] = fmax(mx[a], v[a]); }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn[a] = fmin(mn[a], __shfl_xor(mn[a], o)); mx[a] = fmax(mx[a], __shfl_xor(mx[a], o)); }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (mn[a] <= mx[a]) {   // skips waves that saw no point
+        atomicMin((unsigned long long*)&out6[a], (unsigned long long)enc_f64(mn[a]));
+        atomicMax((unsigned long long*)&out6[3 + a], (unsigned long long)enc_f64(mx[a]));
+      }
+    }
+  }
+}
+__global__ void bbox_init_kernel(uint64_t* out6) {
+  if (threadIdx.x < 3) out6[threadIdx.x] = ~0ull;
+  else if (threadIdx.x < 6) out6[threadIdx.x] = 0ull;
+}
+
+// ---- small table kernels -----------------------------------------------------------------------
+__global__ void single_segment_kernel(uint32_t n, uint32_t tile_pts, uint32_t* seg_start, uint32_t* tile_first) {
+  if (threadIdx.x == 0) { seg_start[0] = 0; seg_start[1] = n; tile_first[0] = 0; tile_first[1] = (n + tile_pts - 1) / tile_pts; }
+}
+// pass-1 histogram -> segment starts, scatter cursors and the tile table of pass 2 (nseg <= 1024)
+__global__ __launch_bounds__(WG) void seg_setup_kernel(const uint32_t* __restrict__ counts, int nseg, uint32_t n, uint32_t tile_pts,
+                                                       uint32_t* start, uint32_t* cursor, uint32_t* tile_first) {
+  __shared__ uint32_t wsum[4];
+  uint32_t c[4], t[4], sc = 0, st = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = threadIdx.x * 4 + i;
+    c[i] = b < nseg ? counts[b] : 0u;
+    t[i] = (c[i] + tile_pts - 1) / tile_pts;
+    sc += c[i]; st += t[i];
+  }
+  uint32_t tot;
+  uint32_t ec = block_excl_scan(sc, wsum, tot);
+  __syncthreads();
+  uint32_t et = block_excl_scan(st, wsum, tot);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = threadIdx.x * 4 + i;
+    if (b < nseg) { start[b] = ec; cursor[b] = ec; tile_first[b] = et; }
+    ec += c[i]; et += t[i];
+  }
+  if (threadIdx.x == 0) { start[nseg] = n; tile_first[nseg] = tot; }
+}
+
+// ---- generic exclusive scan of u32 ---------------------------------------------------------------
+constexpr int SCAN_ITEMS = 8, SCAN_TILE = WG * SCAN_ITEMS;
+__global__ __launch_bounds__(WG) void scan_reduce_kernel(const uint32_t* __restrict__ in, uint32_t n, uint32_t* sums) {
+  __shared__ uint32_t wsum[4];
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) s += in[base + i];
+  uint32_t tot;
+  block_excl_scan(s, wsum, tot);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(WG) void scan_sums_kernel(uint32_t* sums, uint32_t nt) {
+  __shared__ uint32_t wsum[4];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nt; base += WG * 4) {
+    uint32_t c[4], s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const uint32_t j = base + threadIdx.x * 4 + i; c[i] = j < nt ? sums[j] : 0u; s += c[i]; }
+    uint32_t tot;
+    uint32_t e = block_excl_scan(s, wsum, tot) + carry;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const uint32_t j = base + threadIdx.x * 4 + i; if (j < nt) sums[j] = e; e += c[i]; }
+    carry += tot;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(WG) void scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t* out, uint32_t n,
+                                                        const uint32_t* __restrict__ sums) {
+  __shared__ uint32_t wsum[4];
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t c[SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) { c[i] = base + i < n ? in[base + i] : 0u; s += c[i]; }
+  uint32_t tot;
+  uint32_t e = block_excl_scan(s, wsum, tot) + sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < n) out[base + i] = e; e += c[i]; }
+}
+
+// ---- partition pass: histogram -------------------------------------------------------------------
+template <class Loader, int ITEMS>
+__global__ __launch_bounds__(WG) void hist_kernel(Loader in, GridParams gp, BinSpec bs, const uint32_t* __restrict__ seg_start,
+                                                  const uint32_t* __restrict__ tile_first, int nseg, uint32_t* counts, int tiles_per_wg) {
+  __shared__ uint32_t hist[PT_MAXBINS];
+  constexpr uint32_t TILE = WG * ITEMS;
+  int cur_seg = -1;
+  for (int tt = 0; tt < tiles_per_wg; ++tt) {
+    uint32_t seg, s, e;
+    if (!tile_range(seg_start, tile_first, nseg, blockIdx.x * tiles_per_wg + tt, TILE, seg, s, e)) break;
+    if ((int)seg != cur_seg) {
+      __syncthreads();
+      if (cur_seg >= 0)
+        for (int b = threadIdx.x; b < bs.nbins; b += WG) { const uint32_t c = hist[b]; if (c) atomicAdd(&counts[global_bin(bs, cur_seg, b)], c); }
+      __syncthreads();
+      for (int b = threadIdx.x; b < bs.nbins; b += WG) hist[b] = 0;
+      __syncthreads();
+      cur_seg = (int)seg;
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const uint32_t i = s + j * WG + threadIdx.x;
+      if (i < e) atomicAdd(&hist[local_bin(bs, block_of_rec(gp, in.load(i)))], 1u);
+    }
+  }
+  __syncthreads();
+  if (cur_seg >= 0)
+    for (int b = threadIdx.x; b < bs.nbins; b += WG) { const uint32_t c = hist[b]; if (c) atomicAdd(&counts[global_bin(bs, cur_seg, b)], c); }
+}
+
+// ---- partition pass: scatter (one tile per workgroup) ----------------------------------------------
+template <class Loader, int ITEMS>
+__global__ __launch_bounds__(WG) void scatter_kernel(Loader in, typename Loader::Rec* __restrict__ out, GridParams gp, BinSpec bs,
+                                                     const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ tile_first, int nseg,
+                                                     uint32_t* cursor) {
+  using Rec = typename Loader::Rec;
+  constexpr uint32_t TILE = WG * ITEMS;
+  constexpr int BPT = PT_MAXBINS / WG;            // bins per thread in the scan
+  __shared__ uint32_t binA[PT_MAXBINS];           // counts, then local start of each bin in `stage`
+  __shared__ uint32_t binB[PT_MAXBINS];           // global start of the bin's run minus its local start
+  __shared__ uint32_t wsum[4];
+  __shared__ Rec stage[TILE];
+
+  uint32_t seg, s, e;
+  if (!tile_range(seg_start, tile_first, nseg, blockIdx.x, TILE, seg, s, e)) return;
+  for (int b = threadIdx.x; b < PT_MAXBINS; b += WG) binA[b] = 0;
+  __syncthreads();
+
+  Rec r[ITEMS];
+  uint32_t lb[ITEMS], rank[ITEMS];
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const uint32_t i = s + j * WG + threadIdx.x;
+    if (i < e) {
+      r[j] = in.load(i);
+      lb[j] = local_bin(bs, block_of_rec(gp, r[j]));
+      rank[j] = atomicAdd(&binA[lb[j]], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    uint32_t c[BPT], sum = 0;
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) { c[i] = binA[threadIdx.x * BPT + i]; sum += c[i]; }
+    uint32_t tot;
+    uint32_t ex = block_excl_scan(sum, wsum, tot);
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) {
+      const int b = threadIdx.x * BPT + i;
+      binA[b] = ex;
+      if (c[i]) binB[b] = atomicAdd(&cursor[global_bin(bs, seg, b)], c[i]) - ex;   // one reservation per (tile, bin)
+      ex += c[i];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const uint32_t i = s + j * WG + threadIdx.x;
+    if (i < e) stage[binA[lb[j]] + rank[j]] = r[j];
+  }
+  __syncthreads();
+  const uint32_t cnt = e - s;
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const uint32_t slot = j * WG + threadIdx.x;
+    if (slot < cnt) {
+      const Rec v = stage[slot];
+      out[binB[local_bin(bs, block_of_rec(gp, v))] + slot] = v;     // consecutive slots of a bin -> consecutive addresses
+    }
+  }
+}
+
+// ---- finalize: counting sort of one 8x8x8-cell block by local cell, in LDS -------------------------
+template <class Rec>
+__global__ __launch_bounds__(WG) void finalize_kernel(const Rec* __restrict__ in, Rec* __restrict__ out, GridParams gp,
+                                                      const uint32_t* __restrict__ block_start, uint32_t* cell_start) {
+  __shared__ uint32_t cnt[PT_BLOCK_CELLS];
+  __shared__ uint32_t wsum[4];
+  const uint32_t b = blockIdx.x;
+  const uint32_t s = block_start[b], e = block_start[b + 1];
+  if (s == e) {   // empty block: only the table
+    if (cell_start) {
+      cell_start[b * PT_BLOCK_CELLS + threadIdx.x] = s;
+      cell_start[b * PT_BLOCK_CELLS + WG + threadIdx.x] = s;
+      if (b == gridDim.x - 1 && threadIdx.x == 0) cell_start[(b + 1) * PT_BLOCK_CELLS] = e;
+    }
+    return;
+  }
+  cnt[threadIdx.x] = 0; cnt[WG + threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t i = s + threadIdx.x; i < e; i += WG) {
+    int cx, cy, cz;
+    pt_cell_of(gp, in[i], cx, cy, cz);
+    atomicAdd(&cnt[pt_local_cell(cx, cy, cz)], 1u);
+  }
+  __syncthreads();
+  const uint32_t c0 = cnt[2 * threadIdx.x], c1 = cnt[2 * threadIdx.x + 1];
+  uint32_t tot;
+  const uint32_t ex = block_excl_scan(c0 + c1, wsum, tot);
+  __syncthreads();
+  cnt[2 * threadIdx.x] = ex; cnt[2 * threadIdx.x + 1] = ex + c0;     // cursors, relative to s
+  if (cell_start) {
+    cell_start[b * PT_BLOCK_CELLS + 2 * threadIdx.x] = s + ex;
+    cell_start[b * PT_BLOCK_CELLS + 2 * threadIdx.x + 1] = s + ex + c0;
+    if (b == gridDim.x - 1 && threadIdx.x == 0) cell_start[(b + 1) * PT_BLOCK_CELLS] = e;
+  }
+  __syncthreads();
+  for (uint32_t i = s + threadIdx.x; i < e; i += WG) {   // second read is served by L2
+    const Rec v = in[i];
+    int cx, cy, cz;
+    pt_cell_of(gp, v, cx, cy, cz);
+    out[s + atomicAdd(&cnt[pt_local_cell(cx, cy, cz)], 1u)] = v;
+  }
+}
+
+template <class Rec> constexpr int items_for() { return sizeof(Rec) == 16 ? 8 : 4; }
+
+}  // namespace
+
+// =================================================================================================
+int pt_sort_tile_points(size_t rec_size) { return WG * (rec_size == 16 ? 8 : 4); }
+
+void pt_launch_bbox_init(uint64_t* out6, hipStream_t s) { hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, s, out6); }
+template <class T>
+void pt_launch_bbox(const T* x, const T* y, const T* z, uint32_t n, uint64_t* out6, hipStream_t s) {
+  if (!n) return;
+  const uint32_t g = (uint32_t)std::min<uint64_t>(((uint64_t)n + WG - 1) / WG, 2048);
+  hipLaunchKernelGGL(bbox_kernel<T>, dim3(g), dim3(WG), 0, s, x, y, z, n, out6);
+}
+template void pt_launch_bbox<float>(const float*, const float*, const float*, uint32_t, uint64_t*, hipStream_t);
+template void pt_launch_bbox<double>(const double*, const double*, const double*, uint32_t, uint64_t*, hipStream_t);
+double pt_bbox_decode(uint64_t enc) {
+  const uint64_t b = (enc >> 63) ? (enc & 0x7FFFFFFFFFFFFFFFull) : ~enc;
+  double d;
+  memcpy(&d, &b, 8);
+  return d;
+}
+
+void pt_launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* tmp, hipStream_t s) {
+  if (!n) return;
+  const uint32_t nt = (n + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nt), dim3(WG), 0, s, in, n, tmp);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(WG), 0, s, tmp, nt);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nt), dim3(WG), 0, s, in, out, n, tmp);
+}
+
+template <class T, class Rec>
+void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* z, const uint32_t* gidx, uint32_t n, Rec* out_final,
+                         Rec* tmp, uint32_t* cell_start, const SortTables& tb, hipStream_t s) {
+  constexpr int ITEMS = items_for<Rec>();
+  constexpr uint32_t TILE = WG * ITEMS;
+  const uint32_t nblocks = (uint32_t)gp.nblocks;
+  const uint32_t nmacro = nblocks / PT_MACRO_BLOCKS;
+  const uint32_t ntiles = (n + TILE - 1) / TILE;
+  PlanarLoader<T> pl{x, y, z, gidx};
+  (void)hipMemsetAsync(tb.block_count, 0, sizeof(uint32_t) * ((size_t)nblocks + 1), s);
+  hipLaunchKernelGGL(single_segment_kernel, dim3(1), dim3(64), 0, s, n, TILE, tb.seg_start1, tb.tile_first1);
+
+  const Rec* blocked = nullptr;   // records partitioned by block id
+  if (nblocks <= PT_MAXBINS) {
+    // one level: bins = blocks.  planar -> tmp (by block) -> out_final (by cell)
+    static_assert(PT_MAXBINS == 1024, "one-level bin mask assumes 10 bits");
+    const BinSpec bs{1, 10, (int)nblocks};
+    const int tpw = 4;
+    if (n) {
+      hipLaunchKernelGGL((hist_kernel<PlanarLoader<T>, ITEMS>), dim3((ntiles + tpw - 1) / tpw), dim3(WG), 0, s, pl, gp, bs,
+                         tb.seg_start1, tb.tile_first1, 1, tb.block_count, tpw);
+    }
+    pt_launch_scan_u32(tb.block_count, tb.block_start, nblocks + 1, tb.scan_tmp, s);
+    (void)hipMemcpyAsync(tb.cursor2, tb.block_start, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s);
+    if (n)
+      hipLaunchKernelGGL((scatter_kernel<PlanarLoader<T>, ITEMS>), dim3(ntiles), dim3(WG), 0, s, pl, tmp, gp, bs, tb.seg_start1,
+                         tb.tile_first1, 1, tb.cursor2);
+    blocked = tmp;
+    hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(WG), 0, s, blocked, out_final, gp, tb.block_start, cell_start);
+    return;
+  }
+  // two levels: planar -> out_final (by macro block) -> tmp (by block) -> out_final (by cell)
+  const BinSpec b1{0, 9, (int)nmacro};
+  const BinSpec b2{1, 9, PT_MACRO_BLOCKS};
+  (void)hipMemsetAsync(tb.counts1, 0, sizeof(uint32_t) * (PT_MAXBINS + 1), s);
+  if (n) {
+    const int tpw = 8;
+    hipLaunchKernelGGL((hist_kernel<PlanarLoader<T>, ITEMS>), dim3((ntiles + tpw - 1) / tpw), dim3(WG), 0, s, pl, gp, b1,
+                       tb.seg_start1, tb.tile_first1, 1, tb.counts1, tpw);
+  }
+  hipLaunchKernelGGL(seg_setup_kernel, dim3(1), dim3(WG), 0, s, tb.counts1, (int)nmacro, n, TILE, tb.start1, tb.cursor1, tb.tile_first2);
+  if (n)
+    hipLaunchKernelGGL((scatter_kernel<PlanarLoader<T>, ITEMS>), dim3(ntiles), dim3(WG), 0, s, pl, out_final, gp, b1, tb.seg_start1,
+                       tb.tile_first1, 1, tb.cursor1);
+  RecLoader<Rec> rl{out_final};
+  const uint32_t ntiles2 = ntiles + nmacro;   // upper bound: every segment adds at most one partial tile
+  if (n) {
+    const int tpw = 4;
+    hipLaunchKernelGGL((hist_kernel<RecLoader<Rec>, ITEMS>), dim3((ntiles2 + tpw - 1) / tpw), dim3(WG), 0, s, rl, gp, b2, tb.start1,
+                       tb.tile_first2, (int)nmacro, tb.block_count, tpw);
+  }
+  pt_launch_scan_u32(tb.block_count, tb.block_start, nblocks + 1, tb.scan_tmp, s);
+  (void)hipMemcpyAsync(tb.cursor2, tb.block_start, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s);
+  if (n)
+    hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS>), dim3(ntiles2), dim3(WG), 0, s, rl, tmp, gp, b2, tb.start1, tb.tile_first2,
+                       (int)nmacro, tb.cursor2);
+  hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(WG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start);
+}
+template void pt_launch_grid_sort<float, RecF>(const GridParams&, const float*, const float*, const float*, const uint32_t*, uint32_t, RecF*,
+                                               RecF*, uint32_t*, const SortTables&, hipStream_t);
+template void pt_launch_grid_sort<double, RecD>(const GridParams&, const double*, const double*, const double*, const uint32_t*, uint32_t,
+                                                RecD*, RecD*, uint32_t*, const SortTables&, hipStream_t);

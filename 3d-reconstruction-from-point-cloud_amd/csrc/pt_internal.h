@@ -1,0 +1,66 @@
+// pt_internal.h -- host-side launch interface between the C-ABI glue (pt_api.hip) and the kernel
+// translation units (pt_grid.hip, pt_query.hip, pt_attr.hip).  Everything takes the stream to launch on;
+// nothing here allocates or synchronises.
+#pragma once
+#include "pt_common.h"
+
+// tables used by one sort (source cloud or target set)
+struct SortTables {
+  uint32_t* counts1;     // [PT_MAXBINS+1]     pass-1 histogram (macro blocks, or blocks if 1-level)
+  uint32_t* start1;      // [PT_MAXBINS+1]     exclusive scan of counts1 (+ total)
+  uint32_t* cursor1;     // [PT_MAXBINS]
+  uint32_t* tile_first1; // [2]                one segment: {0, ntiles}
+  uint32_t* seg_start1;  // [2]                {0, n}
+  uint32_t* tile_first2; // [PT_MAXBINS+1]     tiles per pass-1 segment, scanned
+  uint32_t* block_count; // [nblocks+1]
+  uint32_t* block_start; // [nblocks+1]
+  uint32_t* cursor2;     // [nblocks]
+  uint32_t* scan_tmp;    // [>= nblocks/2048 + 2]
+};
+
+// ---- pt_grid.hip ------------------------------------------------------------------------------
+// bbox of planar xyz (T = float/double); out6 = orderable-u64 encoded {min xyz, max xyz}; init first.
+void pt_launch_bbox_init(uint64_t* out6, hipStream_t s);
+template <class T> void pt_launch_bbox(const T* x, const T* y, const T* z, uint32_t n, uint64_t* out6, hipStream_t s);
+double pt_bbox_decode(uint64_t enc);
+
+// Sort n points into cell order.  Input either planar (x,y,z[,gidx]) or records; output `out_final`
+// sorted by cell key, `tmp` is scratch of the same size.  cell_start (u32[nblocks*512+1]) is written when
+// non-null.  Rec = RecF (T=float) or RecD (T=double).
+template <class T, class Rec>
+void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* z, const uint32_t* gidx, uint32_t n,
+                         Rec* out_final, Rec* tmp, uint32_t* cell_start, const SortTables& tb, hipStream_t s);
+int pt_sort_tile_points(size_t rec_size);
+
+// generic exclusive scan of u32 (n <= 2048*2048*... see pt_grid.hip); out may alias in
+void pt_launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* tmp, hipStream_t s);
+
+// ---- pt_query.hip -----------------------------------------------------------------------------
+// k-NN of m sorted target records against the sorted source records.  bound2 (may be null) is indexed by
+// the target's id.  Results go to out_idx/out_d2 at row `id` (k entries per row).
+template <class Rec>
+void pt_launch_knn(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const Rec* tgt, uint32_t m, int k,
+                   const double* bound2, uint32_t* out_idx, double* out_d2, hipStream_t s);
+void pt_launch_merge(const uint32_t* idx_lists, const double* d2_lists, int g, uint32_t m, int k, uint32_t* idx_out,
+                     double* d2_out, hipStream_t s);
+template <class T>
+void pt_launch_slab_need(const T* x, const T* y, const T* z, const double* d2, uint32_t m, int k, int axis,
+                         const double* bounds_dev, int g, int my_slab, uint8_t* need, hipStream_t s);
+
+// ---- pt_attr.hip ------------------------------------------------------------------------------
+// SURVEY.md Appendix C generator.  Writes planar xyz (T) for indices [0,n_total) whose `axis` coordinate is
+// in [lo,hi) to x/y/z/gidx, appending through *counter (device u32, zeroed by the caller).
+template <class T>
+void pt_launch_synth_xyz(uint64_t seed, uint64_t stream, uint32_t n_total, int axis, double lo, double hi, T* x, T* y, T* z,
+                         uint32_t* gidx, uint32_t* counter, uint32_t capacity, hipStream_t s);
+void pt_launch_synth_attr(uint64_t seed, uint32_t n_total, Attr* attr, hipStream_t s);
+// reference AoS records (80-B stride, device copy) -> planar f64 xyz + attribute table
+void pt_launch_aos_split(const void* aos, uint32_t n, double* x, double* y, double* z, Attr* attr, hipStream_t s);
+void pt_launch_pack_attr(const uint8_t* rgb, const float* nrm, uint32_t n, Attr* attr, hipStream_t s);
+void pt_launch_blend(const uint32_t* idx, const double* d2, uint32_t m, int k, int mode, const Attr* attr, uint32_t n_attr,
+                     float* rgb_out, float* nrm_out, hipStream_t s);
+template <class T>
+void pt_launch_pca(const uint32_t* idx, uint32_t m, int k, const T* x, const T* y, const T* z, uint32_t n, const Attr* attr,
+                   float* nrm_out, hipStream_t s);
+void pt_launch_iota(uint32_t* p, uint32_t n, hipStream_t s);
+template <class T> void pt_launch_gather_xyz(const T* x, const T* y, const T* z, uint32_t n, T* out_planar, hipStream_t s);

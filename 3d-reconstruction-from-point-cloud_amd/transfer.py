@@ -1,0 +1,213 @@
+"""Host-side mirror of the reference's hot path, over the C ABI.
+
+The reference has no operator/plugin interface for this path: it is three statements of main()
+(reference src/pointsTransfer.cpp):
+    :259      Tree tree(points.begin(), points.end());          -> PointsTransfer.build*()
+    :474-478  K_neighbor_search search(tree, v, K); iterate      -> PointsTransfer.query*()
+    :95-97    the only blend arithmetic (barycentric colour mix) -> PointsTransfer.blend()
+Names below follow those steps.  Arrays are numpy on the host, or raw device pointers / torch
+tensors (anything with .data_ptr()) for the *_dev methods.  Everything runs in libpt_hip.so on the
+GPU; nothing here computes neighbours on the CPU.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import capi
+
+K_REFERENCE = 20   # `const unsigned int K = 20`, reference src/pointsTransfer.cpp:128
+
+
+def _np_type(xyz_type):
+    return np.float64 if xyz_type == capi.F64 else np.float32
+
+
+def _planar(xyz, xyz_type=None):
+    a = np.asarray(xyz)
+    if a.ndim != 2 or a.shape[0] != 3:
+        raise ValueError("xyz must be planar with shape (3, n)")
+    if xyz_type is None:
+        xyz_type = capi.F64 if a.dtype == np.float64 else capi.F32
+    return np.ascontiguousarray(a, dtype=_np_type(xyz_type)), xyz_type
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if hasattr(a, "data_ptr"):      # torch tensor
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(int(a))
+
+
+class PointsTransfer:
+    """One context = one GPU = one (slab of a) source cloud."""
+
+    def __init__(self, device=0, rho=None):
+        self._L = capi.lib()
+        self._h = C.c_void_p()
+        dev = (C.c_int * 1)(device)
+        rc = self._L.pt_ctx_create(C.byref(self._h), dev, 1)
+        if rc != capi.OK:
+            self._h = C.c_void_p()
+            raise capi.PtError(rc, "pt_ctx_create failed (no usable gfx950 device? there is no CPU fallback)")
+        if rho is not None:
+            self.set_param("rho", rho)
+
+    # -- plumbing ------------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != capi.OK:
+            raise capi.PtError(rc, self._L.pt_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.pt_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_param(self, name, value):
+        self._chk(self._L.pt_set_param(self._h, name.encode(), float(value)))
+
+    def set_stream(self, hip_stream):
+        self._chk(self._L.pt_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        self._chk(self._L.pt_synchronize(self._h))
+
+    def stats(self):
+        s = capi.Stats()
+        self._chk(self._L.pt_stats(self._h, C.byref(s)))
+        return {f[0]: (list(getattr(s, f[0])) if f[0] == "grid_dim" else getattr(s, f[0])) for f in s._fields_ if f[0] != "_pad"}
+
+    @property
+    def num_source(self):
+        return int(self._L.pt_num_source(self._h))
+
+    @property
+    def num_targets(self):
+        return int(self._L.pt_num_targets(self._h))
+
+    # -- build (pointsTransfer.cpp:259) -----------------------------------------------------
+    def build_aos(self, points):
+        """points: numpy structured/raw array of the reference's 80-byte Point records."""
+        a = np.ascontiguousarray(points)
+        assert a.dtype.itemsize == 80, "Point records are 80 bytes (reference src/Point.h)"
+        self._chk(self._L.pt_build_aos(self._h, _ptr(a), a.shape[0]))
+
+    def build(self, xyz, rgb=None, nrm=None, xyz_type=None, gidx=None):
+        a, t = _planar(xyz, xyz_type)
+        n = a.shape[1]
+        if gidx is not None:
+            g = np.ascontiguousarray(gidx, dtype=np.uint32)
+            assert g.shape == (n,)
+            self._chk(self._L.pt_build_soa_indexed(self._h, _ptr(a), t, _ptr(g), n, 0))
+            return
+        r = None if rgb is None else np.ascontiguousarray(rgb, dtype=np.uint8)
+        m = None if nrm is None else np.ascontiguousarray(nrm, dtype=np.float32)
+        if r is not None:
+            assert r.shape == (n, 3)
+        if m is not None:
+            assert m.shape == (n, 3)
+        self._chk(self._L.pt_build_soa(self._h, _ptr(a), t, _ptr(r), _ptr(m), n, 0))
+
+    def set_attributes(self, rgb, nrm):
+        r = None if rgb is None else np.ascontiguousarray(rgb, dtype=np.uint8)
+        m = None if nrm is None else np.ascontiguousarray(nrm, dtype=np.float32)
+        n = (r if r is not None else m).shape[0]
+        self._chk(self._L.pt_set_attributes(self._h, _ptr(r), _ptr(m), n, 0))
+
+    def build_synth(self, n_total, seed, xyz_type=capi.F32, dist=capi.DIST_UNIFORM, slab_axis=-1, slab_lo=-math.inf, slab_hi=math.inf):
+        self._chk(self._L.pt_build_synth(self._h, n_total, seed, dist, xyz_type, slab_axis, slab_lo, slab_hi))
+
+    def rebuild(self):
+        self._chk(self._L.pt_rebuild(self._h))
+
+    # -- query (pointsTransfer.cpp:462-479) ---------------------------------------------------
+    def query(self, targets, k=K_REFERENCE, xyz_type=None, want_d2=True):
+        a, t = _planar(targets, xyz_type)
+        m = a.shape[1]
+        idx = np.empty((m, k), np.uint32)
+        d2 = np.empty((m, k), np.float64) if want_d2 else None
+        self._chk(self._L.pt_query_soa(self._h, _ptr(a), t, m, k, 0, _ptr(idx), _ptr(d2)))
+        return (idx, d2) if want_d2 else idx
+
+    def query_aos(self, points, k=K_REFERENCE):
+        a = np.ascontiguousarray(points)
+        assert a.dtype.itemsize == 80
+        m = a.shape[0]
+        idx = np.empty((m, k), np.uint32)
+        d2 = np.empty((m, k), np.float64)
+        self._chk(self._L.pt_query_aos(self._h, _ptr(a), m, k, _ptr(idx), _ptr(d2)))
+        return idx, d2
+
+    def targets_synth(self, m_total, seed, xyz_type=capi.F32, dist=capi.DIST_UNIFORM, slab_axis=-1, slab_lo=-math.inf, slab_hi=math.inf):
+        self._chk(self._L.pt_targets_synth(self._h, m_total, seed, dist, xyz_type, slab_axis, slab_lo, slab_hi))
+
+    def query_resident_dev(self, k, idx_dev, d2_dev=None):
+        self._chk(self._L.pt_query_resident(self._h, k, _ptr(idx_dev), _ptr(d2_dev)))
+
+    def query_dev(self, xyz_dev, xyz_type, m, k, idx_dev, d2_dev=None):
+        self._chk(self._L.pt_query_soa(self._h, _ptr(xyz_dev), xyz_type, m, k, 1, _ptr(idx_dev), _ptr(d2_dev)))
+
+    def query_bounded_dev(self, xyz_dev, xyz_type, bound2_dev, m, k, idx_dev, d2_dev):
+        self._chk(self._L.pt_query_bounded_dev(self._h, _ptr(xyz_dev), xyz_type, _ptr(bound2_dev), m, k, _ptr(idx_dev), _ptr(d2_dev)))
+
+    def resident_target_ids_dev(self, ids_dev):
+        self._chk(self._L.pt_resident_target_ids(self._h, _ptr(ids_dev)))
+
+    def resident_target_xyz_dev(self, xyz_dev):
+        self._chk(self._L.pt_resident_target_xyz(self._h, _ptr(xyz_dev)))
+
+    # -- blend / PCA ----------------------------------------------------------------------------
+    def blend(self, idx, d2=None, mode=capi.BLEND_MEAN):
+        idx = np.ascontiguousarray(idx, np.uint32)
+        m, k = idx.shape
+        d2c = None if d2 is None else np.ascontiguousarray(d2, np.float64)
+        rgb = np.empty((m, 3), np.float32)
+        nrm = np.empty((m, 3), np.float32)
+        self._chk(self._L.pt_blend(self._h, _ptr(idx), _ptr(d2c), m, k, mode, _ptr(rgb), _ptr(nrm)))
+        return rgb, nrm
+
+    def blend_dev(self, idx_dev, d2_dev, m, k, mode, rgb_out_dev, nrm_out_dev):
+        self._chk(self._L.pt_blend_dev(self._h, _ptr(idx_dev), _ptr(d2_dev), m, k, mode, _ptr(rgb_out_dev), _ptr(nrm_out_dev)))
+
+    def pca_normals(self, idx):
+        idx = np.ascontiguousarray(idx, np.uint32)
+        m, k = idx.shape
+        out = np.empty((m, 3), np.float32)
+        self._chk(self._L.pt_pca_normals(self._h, _ptr(idx), m, k, _ptr(out)))
+        return out
+
+    def pca_normals_dev(self, idx_dev, m, k, nrm_out_dev):
+        self._chk(self._L.pt_pca_normals_dev(self._h, _ptr(idx_dev), m, k, _ptr(nrm_out_dev)))
+
+    # -- multi-GPU helpers ---------------------------------------------------------
+    def merge_candidates_dev(self, idx_lists_dev, d2_lists_dev, g, m, k, idx_out_dev, d2_out_dev):
+        self._chk(self._L.pt_merge_candidates_dev(self._h, _ptr(idx_lists_dev), _ptr(d2_lists_dev), g, m, k, _ptr(idx_out_dev), _ptr(d2_out_dev)))
+
+    def slab_need_dev(self, tgt_xyz_dev, xyz_type, d2_dev, m, k, slab_axis, slab_bounds, my_slab, need_dev):
+        b = np.ascontiguousarray(slab_bounds, np.float64)
+        g = b.shape[0] - 1
+        self._chk(self._L.pt_slab_need_dev(self._h, _ptr(tgt_xyz_dev), xyz_type, _ptr(d2_dev), m, k, slab_axis, _ptr(b), g, my_slab, _ptr(need_dev)))
+
+
+POINT_DTYPE = np.dtype({
+    "names": ["ver", "normal", "color", "U", "V"],
+    "formats": [(np.float64, 3), (np.float64, 3), (np.int32, 3), np.float64, np.float64],
+    "offsets": [0, 24, 48, 64, 72],
+    "itemsize": 80,
+})
+"""numpy view of the reference's Point record (reference src/Point.h:2-6)."""

@@ -1,0 +1,283 @@
+"""GPU suite: the HIP path, called through the C ABI, against the CPU oracle and the golden fixtures.
+Bar: neighbour indices and squared distances bit-exact; blended attributes within 1e-5 (colour/255, normals)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _check_exact(got, want, what=""):
+    gi, gd = got
+    wi, wd = want
+    assert np.array_equal(gi, wi), "%s: indices differ in %d of %d rows" % (what, (gi != wi).any(axis=1).sum(), gi.shape[0])
+    assert np.array_equal(gd, wd), "%s: d2 differ" % what
+
+
+@pytest.fixture(scope="module")
+def pt(pkg):
+    p = pkg.PointsTransfer(device=0)
+    yield p
+    p.close()
+
+
+# ---- golden fixtures and the reference-shaped cases -----------------------------------------------------
+@pytest.mark.parametrize("name,ks", [("c1", (1, 8, 16, 32)), ("ties", (1, 8, 20)), ("outside", (8,)), ("tiny", (8, 32)), ("flat", (8,))])
+def test_golden_cases(pt, golden, golden_cases, name, ks):
+    src, tgt = golden_cases[name]
+    pt.build(src)
+    for k in ks:
+        sub = tgt[:, :256] if (name == "c1" and k > 8) else tgt
+        idx, d2 = pt.query(sub, k)
+        _check_exact((idx, d2), (golden["%s_k%d_idx" % (name, k)], golden["%s_k%d_d2" % (name, k)]), "%s k=%d" % (name, k))
+
+
+@pytest.mark.parametrize("n,m,k,seed", [(10000, 1000, 1, 0xC1), (200000, 20000, 8, 0xC2), (300000, 5000, 16, 0xC3), (150000, 3000, 32, 0xC5), (70000, 4000, 20, 7)])
+def test_seeded_uniform_vs_oracle(pt, oracle, n, m, k, seed):
+    src, tgt = oracle.synth_xyz(seed, 0, n), oracle.synth_xyz(seed, 1, m)
+    pt.build(src)
+    got = pt.query(tgt, k)
+    kd = oracle.KdTree(src)
+    _check_exact(got, kd.query(tgt, k), "uniform n=%d k=%d" % (n, k))
+    if n <= 70000:
+        _check_exact(got, oracle.knn_bruteforce(src, tgt, k), "brute force")
+
+
+@pytest.mark.parametrize("rho", [1.0, 3.0, 20.0, 200.0])
+def test_cell_size_does_not_change_results(pkg, oracle, rho):
+    src, tgt = oracle.synth_xyz(11, 0, 60000), oracle.synth_xyz(11, 1, 3000)
+    with pkg.PointsTransfer(device=0, rho=rho) as p:
+        p.build(src)
+        _check_exact(p.query(tgt, 8), oracle.knn_bruteforce(src, tgt, 8), "rho=%g" % rho)
+
+
+def test_device_generator_matches_oracle(pkg, oracle):
+    import torch
+    n, m, k, seed = 100000, 10000, 8, 0xC2
+    with pkg.PointsTransfer(device=0) as p:
+        p.build_synth(n, seed)
+        p.targets_synth(m, seed)
+        assert p.num_source == n and p.num_targets == m
+        xyz = torch.empty((3, m), dtype=torch.float32, device="cuda")
+        p.resident_target_xyz_dev(xyz)
+        assert np.array_equal(xyz.cpu().numpy(), oracle.synth_xyz(seed, 1, m))       # bit-identical generator
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda")
+        d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        p.query_resident_dev(k, idx, d2)
+        torch.cuda.synchronize()
+        src, tgt = oracle.synth_xyz(seed, 0, n), oracle.synth_xyz(seed, 1, m)
+        want = oracle.KdTree(src).query(tgt, k)
+        _check_exact((idx.cpu().numpy().view(np.uint32), d2.cpu().numpy()), want, "device generator")
+        # attributes generated on the device: colours exact, normals to rounding
+        rgb = torch.empty((m, 3), dtype=torch.float32, device="cuda"); nrm = torch.empty((m, 3), dtype=torch.float32, device="cuda")
+        p.blend_dev(idx, d2, m, k, pkg.BLEND_MEAN, rgb, nrm)
+        torch.cuda.synchronize()
+        rc, rn = oracle.blend(want[0], want[1], oracle.synth_rgb(seed, n), oracle.synth_nrm(seed, n), 0)
+        assert np.abs(rgb.cpu().numpy() - rc).max() / 255 <= TOL and np.abs(nrm.cpu().numpy() - rn).max() <= TOL
+
+
+# ---- edge cases the domain has ---------------------------------------------------------------------------
+def test_duplicates_and_exact_ties(pt, oracle):
+    rng = np.random.default_rng(1)
+    base = rng.integers(0, 4, size=(3, 500)).astype(np.float32) / 4          # 64 distinct positions, ~8 copies each
+    src = np.concatenate([base, base, base], axis=1)                         # every point three times
+    tgt = rng.integers(0, 8, size=(3, 300)).astype(np.float32) / 8
+    pt.build(src)
+    for k in (1, 5, 8, 20, 32):
+        _check_exact(pt.query(tgt, k), oracle.knn_bruteforce(src, tgt, k), "dups k=%d" % k)
+
+
+def test_all_points_identical_and_single_point(pt, oracle):
+    src = np.full((3, 100), 0.5, np.float32)
+    tgt = np.array([[0.5, 0.1, 3.0], [0.5, 0.2, -2.0], [0.5, 0.3, 0.5]], np.float32)
+    pt.build(src)
+    _check_exact(pt.query(tgt, 8), oracle.knn_bruteforce(src, tgt, 8), "identical")
+    src1 = np.array([[0.25], [0.5], [0.75]], np.float32)
+    pt.build(src1)
+    _check_exact(pt.query(tgt, 4), oracle.knn_bruteforce(src1, tgt, 4), "single")
+
+
+def test_empty_inputs(pt):
+    pt.build(np.zeros((3, 0), np.float32))
+    idx, d2 = pt.query(np.zeros((3, 5), np.float32) + 0.5, 4)
+    assert (idx == 0xFFFFFFFF).all() and np.isinf(d2).all()
+    pt.build(np.random.default_rng(0).random((3, 100)).astype(np.float32))
+    idx, d2 = pt.query(np.zeros((3, 0), np.float32), 4)
+    assert idx.shape == (0, 4) and d2.shape == (0, 4)
+
+
+def test_ragged_density_and_far_targets(pt, oracle):
+    rng = np.random.default_rng(9)
+    blob = (0.5 + 0.01 * rng.standard_normal((3, 30000))).astype(np.float32)       # one dense blob ...
+    sparse = rng.random((3, 2000)).astype(np.float32)                               # ... in a sparse box
+    src = np.concatenate([blob, sparse], axis=1)
+    tgt = np.concatenate([rng.random((3, 500)), 0.5 + 0.02 * rng.standard_normal((3, 500)), 3 * rng.random((3, 100)) - 1], axis=1).astype(np.float32)
+    pt.build(src)
+    for k in (8, 20):
+        _check_exact(pt.query(tgt, k), oracle.KdTree(src).query(tgt, k), "ragged k=%d" % k)
+
+
+def test_k_bounds_and_call_order(pkg, pt):
+    with pkg.PointsTransfer(device=0) as p:
+        with pytest.raises(pkg.PtError) as e:
+            p.query(np.zeros((3, 1), np.float32), 4)
+        assert e.value.code == pkg.capi.ERR_STATE
+    pt.build(np.random.default_rng(0).random((3, 50)).astype(np.float32))
+    for bad in (0, 33):
+        with pytest.raises(pkg.PtError) as e:
+            pt.query(np.zeros((3, 1), np.float32), bad)
+        assert e.value.code == pkg.capi.ERR_ARG
+    with pytest.raises(pkg.PtError):
+        pt.query(np.zeros((3, 1), np.float64), 4)          # f64 targets against an f32 cloud
+
+
+# ---- the reference's own record type: AoS Point, double coordinates ------------------------------------------
+def test_aos_point_records_double_path(pkg, pt, oracle):
+    rng = np.random.default_rng(4)
+    n, m, k = 40000, 2000, 20                                                    # K = 20 as the reference
+    cloud = np.zeros(n, dtype=pkg.POINT_DTYPE)
+    cloud["ver"] = rng.random((n, 3)) * [10.0, 3.0, 1.0] - [5.0, 0, 0]           # doubles that are not fp32-representable
+    cloud["normal"] = rng.standard_normal((n, 3))
+    cloud["color"] = rng.integers(0, 256, (n, 3))
+    verts = np.zeros(m, dtype=pkg.POINT_DTYPE)
+    verts["ver"] = rng.random((m, 3)) * [10.0, 3.0, 1.0] - [5.0, 0, 0]
+    pt.build_aos(cloud)
+    idx, d2 = pt.query_aos(verts, k)
+    want = oracle.knn_bruteforce(cloud["ver"].T, verts["ver"].T, k)
+    _check_exact((idx, d2), want, "AoS f64")
+    c, nn = pt.blend(idx, d2, pkg.BLEND_MEAN)
+    rc, rn = oracle.blend(want[0], want[1], cloud["color"].astype(np.uint8), cloud["normal"].astype(np.float32), 0)
+    assert np.abs(c - rc).max() / 255 <= TOL and np.abs(nn - rn).max() <= TOL
+    # planar f64 entry point gives the same
+    pt.build(cloud["ver"].T.copy(), xyz_type=pkg.F64)
+    _check_exact(pt.query(verts["ver"].T.copy(), k, xyz_type=pkg.F64), want, "planar f64")
+
+
+# ---- blend and PCA -------------------------------------------------------------------------------------------
+def test_blend_modes_match_golden(pt, oracle, golden, golden_cases):
+    src, tgt = golden_cases["c1"]
+    rgb, nrm = oracle.synth_rgb(0xC1, 10000), oracle.synth_nrm(0xC1, 10000)
+    pt.build(src, rgb, nrm)
+    idx, d2 = pt.query(tgt, 8)
+    for mode in (0, 1):
+        c, n = pt.blend(idx, d2, mode)
+        assert np.abs(c - golden["c1_k8_blend%d_rgb" % mode]).max() / 255 <= TOL
+        assert np.abs(n - golden["c1_k8_blend%d_nrm" % mode]).max() <= TOL
+    # missing neighbours (k > N) are skipped by the blend
+    pt.build(src[:, :5], rgb[:5], nrm[:5])
+    idx, d2 = pt.query(tgt[:, :10], 8)
+    c, n = pt.blend(idx, d2, 0)
+    rc, rn = oracle.blend(idx, d2, rgb[:5], nrm[:5], 0)
+    assert np.abs(c - rc).max() / 255 <= TOL and np.abs(n - rn).max() <= TOL
+
+
+def test_pca_normals(pt, oracle):
+    rng = np.random.default_rng(5)
+    n = 50000
+    src = rng.random((3, n)).astype(np.float32)
+    src[2] = (0.3 + 0.1 * src[0] + 0.05 * np.sin(6 * src[1]) + 1e-3 * rng.standard_normal(n)).astype(np.float32)   # a noisy surface
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (n, 1))
+    tgt = src[:, :3000].copy()
+    pt.build(src, None, nrm)
+    idx, d2 = pt.query(tgt, 16)
+    got = pt.pca_normals(idx)
+    want, plan = oracle.pca_normals(idx, src, nrm)
+    ok = plan < 0.1                                  # well-conditioned neighbourhoods
+    assert ok.mean() > 0.9
+    assert np.abs(got[ok] - want[ok]).max() <= TOL
+    assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-5 and (got[ok][:, 2] > 0).all()
+
+
+# ---- multi-GPU pieces on one device: G logical slabs through the same kernels ---------------------------------
+@pytest.mark.parametrize("g", [2, 4])
+def test_logical_slabs_merge_equals_global(pkg, oracle, g):
+    import torch
+    n, m, k, seed = 120000, 6000, 8, 0xC4
+    src, tgt = oracle.synth_xyz(seed, 0, n), oracle.synth_xyz(seed, 1, m)
+    want = oracle.KdTree(src).query(tgt, k)
+    bounds = np.concatenate([[-math.inf], np.quantile(src[0], np.arange(1, g) / g), [math.inf]])
+    li = torch.empty((g, m, k), dtype=torch.int32, device="cuda"); ld = torch.empty((g, m, k), dtype=torch.float64, device="cuda")
+    tx = torch.from_numpy(tgt).cuda()
+    ctxs = []
+    for s in range(g):
+        p = pkg.PointsTransfer(device=0)
+        p.build_synth(n, seed, slab_axis=0, slab_lo=bounds[s], slab_hi=bounds[s + 1])
+        ctxs.append(p)
+    assert sum(p.num_source for p in ctxs) == n
+    for s, p in enumerate(ctxs):            # v0: every slab answers every target, then one G-way merge
+        p.query_dev(tx, pkg.F32, m, k, li[s], ld[s])
+    oi = torch.empty((m, k), dtype=torch.int32, device="cuda"); od = torch.empty((m, k), dtype=torch.float64, device="cuda")
+    ctxs[0].merge_candidates_dev(li, ld, g, m, k, oi, od)
+    torch.cuda.synchronize()
+    _check_exact((oi.cpu().numpy().view(np.uint32), od.cpu().numpy()), want, "v0 merge g=%d" % g)
+    # v2: home slab first, then only the slabs the need-mask names, bounded by the current k-th distance
+    home = np.clip(np.searchsorted(bounds, tgt[0], side="right") - 1, 0, g - 1)
+    fi = np.full((m, k), 0xFFFFFFFF, np.uint32); fd = np.full((m, k), np.inf)
+    total_foreign = 0
+    for s, p in enumerate(ctxs):
+        mine = np.nonzero(home == s)[0]
+        ms = len(mine)
+        txs = torch.from_numpy(np.ascontiguousarray(tgt[:, mine])).cuda()
+        hi_ = torch.empty((ms, k), dtype=torch.int32, device="cuda"); hd_ = torch.empty((ms, k), dtype=torch.float64, device="cuda")
+        p.query_dev(txs, pkg.F32, ms, k, hi_, hd_)
+        need = torch.empty((g, ms), dtype=torch.uint8, device="cuda")
+        p.slab_need_dev(txs, pkg.F32, hd_, ms, k, 0, bounds, s, need)
+        torch.cuda.synchronize()
+        need_h = need.cpu().numpy()
+        assert not need_h[s].any()
+        lists_i = [hi_]; lists_d = [hd_]
+        for s2, p2 in enumerate(ctxs):
+            sel = np.nonzero(need_h[s2])[0]
+            ci = torch.full((ms, k), -1, dtype=torch.int32, device="cuda"); cd = torch.full((ms, k), math.inf, dtype=torch.float64, device="cuda")
+            if s2 != s and len(sel):
+                total_foreign += len(sel)
+                sx = torch.from_numpy(np.ascontiguousarray(tgt[:, mine[sel]])).cuda()
+                bnd = hd_[torch.from_numpy(sel).cuda(), k - 1].contiguous()
+                ri = torch.empty((len(sel), k), dtype=torch.int32, device="cuda"); rd = torch.empty((len(sel), k), dtype=torch.float64, device="cuda")
+                p2.query_bounded_dev(sx, pkg.F32, bnd, len(sel), k, ri, rd)
+                ci[torch.from_numpy(sel).cuda()] = ri; cd[torch.from_numpy(sel).cuda()] = rd
+            if s2 != s:
+                lists_i.append(ci); lists_d.append(cd)
+        Li = torch.stack(lists_i).contiguous(); Ld = torch.stack(lists_d).contiguous()
+        mi = torch.empty((ms, k), dtype=torch.int32, device="cuda"); md = torch.empty((ms, k), dtype=torch.float64, device="cuda")
+        p.merge_candidates_dev(Li, Ld, g, ms, k, mi, md)
+        torch.cuda.synchronize()
+        fi[mine] = mi.cpu().numpy().view(np.uint32); fd[mine] = md.cpu().numpy()
+    _check_exact((fi, fd), want, "v2 pruned g=%d" % g)
+    assert total_foreign < 0.25 * m * (g - 1)           # the pruning really prunes
+    for p in ctxs:
+        p.close()
+
+
+# ---- BASELINE config 2 at full size: size-independent properties + sampled exactness ----------------------------
+def test_full_size_c2_properties(pkg, oracle):
+    import torch
+    n, m, k, seed = 10_000_000, 1_000_000, 8, 0xC2
+    with pkg.PointsTransfer(device=0) as p:
+        p.build_synth(n, seed)
+        p.targets_synth(m, seed)
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        p.query_resident_dev(k, idx, d2)
+        torch.cuda.synchronize()
+        st = p.stats()
+        idx2 = torch.empty_like(idx); d22 = torch.empty_like(d2)
+        p.rebuild(); p.query_resident_dev(k, idx2, d22)                    # idempotence: rebuild + re-query is bit-identical
+        torch.cuda.synchronize()
+        assert torch.equal(idx, idx2) and torch.equal(d2, d22)
+    I = idx.cpu().numpy().view(np.uint32); D = d2.cpu().numpy()
+    assert I.max() < n and (np.diff(D, axis=1) >= 0).all()                  # valid, ascending
+    tie = np.diff(D, axis=1) == 0
+    assert (np.diff(I.astype(np.int64), axis=1)[tie] > 0).all()             # ties broken by index
+    assert (np.sort(I, axis=1)[:, 1:] != np.sort(I, axis=1)[:, :-1]).all()  # no neighbour twice
+    src, tgt = oracle.synth_xyz(seed, 0, n), oracle.synth_xyz(seed, 1, m)
+    # returned distances are the metric of the returned indices (checksum over all rows)
+    dx = tgt[0].astype(np.float64)[:, None] - src[0][I]; dy = tgt[1].astype(np.float64)[:, None] - src[1][I]; dz = tgt[2].astype(np.float64)[:, None] - src[2][I]
+    assert np.array_equal((dx * dx + dy * dy) + dz * dz, D)
+    # exactness on a sample, against the CPU kd-tree restatement over the full cloud
+    sel = np.random.default_rng(0).choice(m, 20000, replace=False)
+    wi, wd = oracle.KdTree(src).query(tgt[:, sel], k)
+    assert np.array_equal(I[sel], wi) and np.array_equal(D[sel], wd)
+    assert st["n_source"] == n and st["n_target"] == m and st["ms_query"] > 0
