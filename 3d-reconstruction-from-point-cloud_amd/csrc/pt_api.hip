@@ -33,6 +33,7 @@ struct pt_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t sev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per-kernel marks of the source sort
   std::string err;
   double rho = 8.0;
   int sync = 1;
@@ -128,6 +129,7 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks) {
   tb.block_start = p; p += (size_t)nblocks + 8;
   tb.cursor2 = p; p += (size_t)nblocks + 8;
   tb.scan_tmp = p;
+  tb.ev = nullptr;
   return PT_OK;
 }
 
@@ -191,6 +193,7 @@ int rebuild(pt_ctx* c) {
   RES(c, c->rec, std::max<size_t>(c->n, 1) * recsize(c->src_type));
   RES(c, c->rec_tmp, std::max<size_t>(c->n, 1) * recsize(c->src_type));
   { int r = make_tables(c, c->stb_mem, c->stb, nblocks); if (r != PT_OK) return r; }
+  c->stb.ev = c->sev;
   if (c->src_type == PT_F32) run_source_sort<float, RecF>(c); else run_source_sort<double, RecD>(c);
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   HIPCHK(c, hipGetLastError());
@@ -207,6 +210,12 @@ int rebuild(pt_ctx* c) {
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->st.ms_build = ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->sev[0]));
+    c->st.ms_kernel[0] = ms;
+    for (int i = 0; i < 5; ++i) {
+      HIPCHK(c, hipEventElapsedTime(&ms, c->sev[i], c->sev[i + 1]));
+      c->st.ms_kernel[1 + i] = ms;
+    }
   }
   return PT_OK;
 }
@@ -259,6 +268,8 @@ int query_resident(pt_ctx* c, int k, const double* bound2_dev, uint32_t* idx_dev
     HIPCHK(c, hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
     c->st.ms_sort_targets = a;
     c->st.ms_query = b;
+    c->st.ms_kernel[6] = a;
+    c->st.ms_kernel[7] = b;
   }
   return PT_OK;
 }
@@ -295,6 +306,8 @@ int pt_ctx_create(pt_ctx** out, const int* device_ids, int n_devices) {
   c->stream = c->own_stream;
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return PT_ERR_HIP; }
+  for (auto& e : c->sev)
+    if (hipEventCreate(&e) != hipSuccess) { delete c; return PT_ERR_HIP; }
   if (hipHostMalloc((void**)&c->h_bbox, 8 * sizeof(uint64_t)) != hipSuccess || hipHostMalloc((void**)&c->h_counter, 64) != hipSuccess) {
     delete c;
     return PT_ERR_HIP;
@@ -314,6 +327,7 @@ void pt_ctx_destroy(pt_ctx* c) {
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->sev) if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }

@@ -387,6 +387,8 @@ void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* 
   const uint32_t nmacro = nblocks / PT_MACRO_BLOCKS;
   const uint32_t ntiles = (n + TILE - 1) / TILE;
   PlanarLoader<T> pl{x, y, z, gidx};
+  auto mark = [&](int i) { if (tb.ev) (void)hipEventRecord(tb.ev[i], s); };
+  mark(0);
   (void)hipMemsetAsync(tb.block_count, 0, sizeof(uint32_t) * ((size_t)nblocks + 1), s);
   hipLaunchKernelGGL(single_segment_kernel, dim3(1), dim3(64), 0, s, n, TILE, tb.seg_start1, tb.tile_first1);
 
@@ -402,11 +404,14 @@ void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* 
     }
     pt_launch_scan_u32(tb.block_count, tb.block_start, nblocks + 1, tb.scan_tmp, s);
     (void)hipMemcpyAsync(tb.cursor2, tb.block_start, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s);
+    mark(1); mark(2); mark(3);
     if (n)
       hipLaunchKernelGGL((scatter_kernel<PlanarLoader<T>, ITEMS>), dim3(ntiles), dim3(WG), 0, s, pl, tmp, gp, bs, tb.seg_start1,
                          tb.tile_first1, 1, tb.cursor2);
+    mark(4);
     blocked = tmp;
     hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(WG), 0, s, blocked, out_final, gp, tb.block_start, cell_start);
+    mark(5);
     return;
   }
   // two levels: planar -> out_final (by macro block) -> tmp (by block) -> out_final (by cell)
@@ -419,9 +424,11 @@ void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* 
                        tb.seg_start1, tb.tile_first1, 1, tb.counts1, tpw);
   }
   hipLaunchKernelGGL(seg_setup_kernel, dim3(1), dim3(WG), 0, s, tb.counts1, (int)nmacro, n, TILE, tb.start1, tb.cursor1, tb.tile_first2);
+  mark(1);
   if (n)
     hipLaunchKernelGGL((scatter_kernel<PlanarLoader<T>, ITEMS>), dim3(ntiles), dim3(WG), 0, s, pl, out_final, gp, b1, tb.seg_start1,
                        tb.tile_first1, 1, tb.cursor1);
+  mark(2);
   RecLoader<Rec> rl{out_final};
   const uint32_t ntiles2 = ntiles + nmacro;   // upper bound: every segment adds at most one partial tile
   if (n) {
@@ -431,10 +438,13 @@ void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* 
   }
   pt_launch_scan_u32(tb.block_count, tb.block_start, nblocks + 1, tb.scan_tmp, s);
   (void)hipMemcpyAsync(tb.cursor2, tb.block_start, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s);
+  mark(3);
   if (n)
     hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS>), dim3(ntiles2), dim3(WG), 0, s, rl, tmp, gp, b2, tb.start1, tb.tile_first2,
                        (int)nmacro, tb.cursor2);
+  mark(4);
   hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(WG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start);
+  mark(5);
 }
 template void pt_launch_grid_sort<float, RecF>(const GridParams&, const float*, const float*, const float*, const uint32_t*, uint32_t, RecF*,
                                                RecF*, uint32_t*, const SortTables&, hipStream_t);

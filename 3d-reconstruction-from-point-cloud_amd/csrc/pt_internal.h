@@ -16,6 +16,7 @@ struct SortTables {
   uint32_t* block_start; // [nblocks+1]
   uint32_t* cursor2;     // [nblocks]
   uint32_t* scan_tmp;    // [>= nblocks/2048 + 2]
+  hipEvent_t* ev;        // optional [6]: start, after hist1, scatter1, hist2+scan, scatter2, finalize (null = no timing)
 };
 
 // ---- pt_grid.hip ------------------------------------------------------------------------------
@@ -63,4 +64,3 @@ template <class T>
 void pt_launch_pca(const uint32_t* idx, uint32_t m, int k, const T* x, const T* y, const T* z, uint32_t n, const Attr* attr,
                    float* nrm_out, hipStream_t s);
 void pt_launch_iota(uint32_t* p, uint32_t n, hipStream_t s);
-template <class T> void pt_launch_gather_xyz(const T* x, const T* y, const T* z, uint32_t n, T* out_planar, hipStream_t s);

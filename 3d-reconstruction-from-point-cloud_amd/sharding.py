@@ -1,0 +1,181 @@
+"""Spatial-slab sharding of the detail-transfer path across GPUs (one process per GPU).
+
+The reference is a single process; all of this is new design, following SURVEY.md 8(e):
+
+  * the source cloud is cut into G slabs along one axis at equal-count quantiles; rank g holds slab g, builds its
+    own grid over it, and keeps ORIGINAL (global) point indices;
+  * every target has a HOME slab (the one its coordinate falls in); the home rank answers it first;
+  * a target needs another slab s only if dist2(target, slab s) <= its current k-th squared distance -- the
+    reference's Distance::min_distance_to_rectangle (src/Distance.h:27-57) applied to slab boxes;
+  * the (few) targets that need other slabs are exchanged with ONE all-gather of request packets, answered by the
+    owning ranks with a radius-bounded search, and returned with ONE all-gather of candidate packets; the home
+    rank merges its own k with the returned k's under the total order (d2, index).
+    north_star: "each GPU returning its local k candidates with an RCCL allgather over xGMI to merge".
+
+Collectives are torch.distributed all_gather (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).  The
+compute steps go through a small engine interface so that the CPU tests can drive the very same protocol code
+with an oracle-backed engine; the GPU engine below calls libpt_hip.so only.
+"""
+import math
+
+import torch
+
+NOIDX = 0xFFFFFFFF
+
+
+# ---- collectives -------------------------------------------------------------------------------------------
+class TorchDistComm:
+    """torch.distributed front-end: the only thing the protocol needs is a same-shape all_gather and a max."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._d = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_gather(self, t):
+        # concatenated form (world * rows, ...): accepted by both RCCL and gloo; viewed as [world, rows, ...]
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self._d.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        return out.view((self.world,) + tuple(t.shape))
+
+    def max_int(self, v, device):
+        t = torch.tensor([int(v)], dtype=torch.int64, device=device)
+        self._d.all_reduce(t, op=self._d.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+
+class SingleComm:
+    """world_size 1 (no exchange ever happens)."""
+    rank, world = 0, 1
+
+    def all_gather(self, t):
+        return t.unsqueeze(0)
+
+    def max_int(self, v, device):
+        return int(v)
+
+
+# ---- slab geometry -----------------------------------------------------------------------------------------
+def uniform_slab_bounds(world, lo=0.0, hi=1.0):
+    """Equal-count quantiles of a uniform cloud on [lo, hi): G+1 ascending bounds, open-ended at both ends."""
+    b = [lo + (hi - lo) * g / world for g in range(world + 1)]
+    b[0], b[-1] = -math.inf, math.inf
+    return b
+
+
+def quantile_slab_bounds(coords, world):
+    """Equal-count quantiles from a (sample of the) cloud's coordinates along the slab axis (1-D tensor)."""
+    q = torch.quantile(coords.double().cpu(), torch.arange(1, world, dtype=torch.float64) / world) if world > 1 else torch.empty(0)
+    return [-math.inf] + [float(v) for v in q] + [math.inf]
+
+
+# ---- engines -------------------------------------------------------------------------------------------------
+class GpuSlabEngine:
+    """The compute steps of the protocol on the GPU, through the C ABI (PointsTransfer)."""
+
+    def __init__(self, pt, xyz_type, device):
+        from . import capi
+        self.pt, self.xyz_type, self.device = pt, xyz_type, device
+        self.tdtype = torch.float64 if xyz_type == capi.F64 else torch.float32
+
+    def slab_need(self, xyz, d2, k, axis, bounds, my_slab):
+        m = xyz.shape[1]
+        need = torch.empty((len(bounds) - 1, m), dtype=torch.uint8, device=self.device)
+        if m:
+            self.pt.slab_need_dev(xyz, self.xyz_type, d2, m, k, axis, bounds, my_slab, need)
+        return need
+
+    def bounded_query(self, xyz, bound2, k):
+        c = xyz.shape[1]
+        idx = torch.empty((c, k), dtype=torch.int32, device=self.device)
+        d2 = torch.empty((c, k), dtype=torch.float64, device=self.device)
+        if c:
+            self.pt.query_bounded_dev(xyz.contiguous(), self.xyz_type, bound2.contiguous(), c, k, idx, d2)
+        return idx, d2
+
+    def merge(self, idx_lists, d2_lists):
+        g, c, k = idx_lists.shape
+        idx = torch.empty((c, k), dtype=torch.int32, device=self.device)
+        d2 = torch.empty((c, k), dtype=torch.float64, device=self.device)
+        if c:
+            self.pt.merge_candidates_dev(idx_lists.contiguous(), d2_lists.contiguous(), g, c, k, idx, d2)
+        return idx, d2
+
+
+# ---- the protocol ------------------------------------------------------------------------------------------------
+def _idx_to_f64(idx_i32):
+    return (idx_i32.to(torch.int64) & 0xFFFFFFFF).to(torch.float64)        # u32 values are exact in f64
+
+
+def _f64_to_idx(v):
+    u = v.to(torch.int64)
+    return torch.where(u >= 2**31, u - 2**32, u).to(torch.int32)          # back to the u32 bit pattern
+
+
+def exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds):
+    """Complete the home-slab answers (idx int32 [m,k] holding u32 bit patterns, d2 f64 [m,k], updated IN PLACE)
+    with the candidates of the other slabs.  xyz: [3,m] planar coordinates of this rank's targets.
+    Returns counters: targets sent out, foreign targets answered, bytes all-gathered per rank."""
+    G, me = comm.world, comm.rank
+    stats = {"crossing": 0, "answered": 0, "bytes_gathered": 0}
+    if G == 1:
+        return stats
+    assert G <= 52, "the need bitmask travels as an exact integer in one f64"
+    dev = idx.device
+    m = xyz.shape[1]
+    need = engine.slab_need(xyz, d2, k, axis, bounds, me)                     # [G, m] u8
+    sel = torch.nonzero(need.any(dim=0)).flatten()                           # my targets that need another slab
+    c = int(sel.numel())
+    weights = (2.0 ** torch.arange(G, dtype=torch.float64, device=dev)).unsqueeze(1)
+    # -- request packets: x, y, z, bound (current k-th d2), slab bitmask ------------------------------------------
+    cmax = comm.max_int(c, dev)
+    stats["crossing"] = c
+    if cmax == 0:
+        return stats
+    pkt = torch.zeros((cmax, 5), dtype=torch.float64, device=dev)
+    if c:
+        pkt[:c, 0:3] = xyz[:, sel].t().to(torch.float64)
+        pkt[:c, 3] = d2[sel, k - 1]
+        pkt[:c, 4] = (need[:, sel].to(torch.float64) * weights).sum(dim=0)
+    allreq = comm.all_gather(pkt)                                             # [G, cmax, 5]
+    stats["bytes_gathered"] += allreq.numel() * 8
+    # -- answer the requests addressed to my slab ---------------------------------------------------------------
+    mask = allreq[:, :, 4].to(torch.int64)
+    mine = ((mask >> me) & 1).bool()
+    mine[me] = False
+    who = torch.nonzero(mine)                                                 # [q, 2] = (owner rank, row in its packet)
+    q = int(who.shape[0])
+    stats["answered"] = q
+    rows = allreq[who[:, 0], who[:, 1]] if q else torch.zeros((0, 5), dtype=torch.float64, device=dev)
+    qxyz = rows[:, 0:3].t().contiguous().to(xyz.dtype)                        # exact: they were widened from this dtype
+    ai, ad = engine.bounded_query(qxyz, rows[:, 3].contiguous(), k)
+    qmax = comm.max_int(q, dev)
+    if qmax == 0:            # cannot happen when cmax > 0, but never all-gather an empty tensor
+        return stats
+    ans = torch.full((qmax, 2 + 2 * k), -1.0, dtype=torch.float64, device=dev)
+    if q:
+        ans[:q, 0] = who[:, 0].to(torch.float64)
+        ans[:q, 1] = who[:, 1].to(torch.float64)
+        ans[:q, 2:2 + k] = ad
+        ans[:q, 2 + k:] = _idx_to_f64(ai)
+    allans = comm.all_gather(ans)                                             # [G, qmax, 2+2k]
+    stats["bytes_gathered"] += allans.numel() * 8
+    # -- merge what came back for my targets ----------------------------------------------------------------------
+    if c == 0:
+        return stats
+    li = torch.full((G, c, k), -1, dtype=torch.int32, device=dev)             # -1 = 0xFFFFFFFF = empty
+    ld = torch.full((G, c, k), math.inf, dtype=torch.float64, device=dev)
+    li[me] = idx[sel]
+    ld[me] = d2[sel]
+    back = torch.nonzero(allans[:, :, 0] == float(me))                       # (server rank, row)
+    if back.numel():
+        rec = allans[back[:, 0], back[:, 1]]
+        prow = rec[:, 1].to(torch.int64)
+        li[back[:, 0], prow] = _f64_to_idx(rec[:, 2 + k:])
+        ld[back[:, 0], prow] = rec[:, 2:2 + k]
+    mi, md = engine.merge(li, ld)
+    idx[sel] = mi
+    d2[sel] = md
+    return stats

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the detail-transfer hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+    grid build over the source cloud  ->  target binning  ->  k-NN search  ->  [slab exchange + merge]  ->  blend
+Metric (BASELINE.json): target points/sec (k=8 detail transfer); value = targets of the WHOLE job / time.
+Default workload = BASELINE config 4, the one north_star quotes the target on: 1B-point source / 50M targets /
+k=8, uniform fp32, seed 0xC4 (fits one MI355X: ~63 GB).  With --gpus N the same cloud is sharded by spatial
+slab over N ranks (strong scaling: total work fixed), one process per GPU, RCCL via torch.distributed.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C4] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract fields + "roofline" + "cpu_baseline" + per-phase detail).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (N source, M target, k, seed)  -- SURVEY.md 8(d)
+    "C2": (10_000_000, 1_000_000, 8, 0xC2),
+    "C3": (100_000_000, 10_000_000, 16, 0xC3),
+    "C4": (1_000_000_000, 50_000_000, 8, 0xC4),
+}
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+KERNEL_NAMES = ["bbox_reduce", "pass1_histogram", "pass1_scatter", "pass2_histogram_scan", "pass2_scatter", "finalize_cellsort",
+                "target_sort", "knn_query"]
+
+
+def kernel_alg_bytes(name, n, m, k, s=12):
+    """Algorithmic HBM bytes ONE launch of that kernel must move: inputs read once + outputs
+    written once.  s = bytes per xyz (12 for fp32); records are s+4 (xyz + original index)."""
+    rec = s + 4
+    return {
+        "bbox_reduce": n * s,
+        "pass1_histogram": n * s,
+        "pass1_scatter": n * (s + rec),
+        "pass2_histogram_scan": n * rec,
+        "pass2_scatter": n * 2 * rec,
+        "finalize_cellsort": n * 2 * rec,
+        "target_sort": m * (s + rec),
+        "knn_query": n * rec + m * rec + m * k * 12,      # scan every source record once, read targets, write idx + d2
+    }[name]
+
+
+def cpu_baseline(n_total, m_total, k, seed):
+    """The oracle's kd-tree restatement of the reference's CPU search (kind "port"), timed on this host's cores on a
+    bounded sample with the workload's N/M ratio.  Reported beside the GPU number -- never the target."""
+    from oracle import oracle as O
+    O.build()
+    ratio = max(1, n_total // max(m_total, 1))
+    ns = min(n_total, 4_000_000)
+    ms = max(1000, min(m_total, ns // ratio))
+    src = O.synth_xyz(seed, 0, ns)
+    tgt = O.synth_xyz(seed, 1, ms)
+    t0 = time.perf_counter()
+    kd = O.KdTree(src)                       # single-threaded, like the reference's CGAL build
+    t1 = time.perf_counter()
+    kd.query(tgt, k)                         # OpenMP over targets, all host cores
+    t2 = time.perf_counter()
+    kd.close()
+    cores = O.num_threads()
+    return {
+        "value": ms / (t2 - t0), "unit": "target points/sec", "cores": cores, "kind": "port",
+        "sample": "first %d of %d source points and first %d of %d targets (same N/M ratio, same generator/seed), k=%d; "
+                  "kd-tree build %.2f s on 1 thread + query %.3f s on %d threads; value = sample targets / (build + query)"
+                  % (ns, n_total, ms, m_total, k, t1 - t0, t2 - t1, cores),
+        "query_only_value": ms / (t2 - t1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    from pt_amd import sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+        comm = sharding.TorchDistComm()
+    else:
+        comm = sharding.SingleComm()
+
+    n_total, m_total, k, seed = WORKLOADS[args.workload]
+    axis = 0
+    bounds = sharding.uniform_slab_bounds(world)
+    pt = pkg.PointsTransfer(device=local_rank)
+    if world > 1:
+        pt.build_synth(n_total, seed, slab_axis=axis, slab_lo=bounds[rank], slab_hi=bounds[rank + 1])
+        pt.targets_synth(m_total, seed, slab_axis=axis, slab_lo=bounds[rank], slab_hi=bounds[rank + 1])
+    else:
+        pt.build_synth(n_total, seed)
+        pt.targets_synth(m_total, seed)
+    n_loc, m_loc = pt.num_source, pt.num_targets
+    idx = torch.empty((m_loc, k), dtype=torch.int32, device=dev)
+    d2 = torch.empty((m_loc, k), dtype=torch.float64, device=dev)
+    rgb = torch.empty((m_loc, 3), dtype=torch.float32, device=dev)
+    nrm = torch.empty((m_loc, 3), dtype=torch.float32, device=dev)
+    xyz = torch.empty((3, m_loc), dtype=torch.float32, device=dev)
+    pt.resident_target_xyz_dev(xyz)
+    engine = sharding.GpuSlabEngine(pt, pkg.F32, dev)
+
+    kms = [0.0] * 8
+    phase = {"build": 0.0, "target_sort": 0.0, "knn": 0.0, "blend": 0.0}
+    xstats = {}
+
+    def step(record):
+        pt.rebuild()
+        pt.query_resident_dev(k, idx, d2)
+        xs = sharding.exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds)
+        pt.blend_dev(idx, d2, m_loc, k, pkg.BLEND_MEAN, rgb, nrm)
+        if record:
+            st = pt.stats()          # HIP-event times of this step's launches, on the stream they ran on
+            for i in range(8):
+                kms[i] += st["ms_kernel"][i]
+            phase["build"] += st["ms_build"]; phase["target_sort"] += st["ms_sort_targets"]
+            phase["knn"] += st["ms_query"]; phase["blend"] += st["ms_blend"]
+            xstats.update(xs)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = m_total * args.steps / dt
+
+    if rank == 0:
+        K = args.steps
+        kavg = [v / K for v in kms]
+        dom = max(range(8), key=lambda i: kavg[i])
+        alg = kernel_alg_bytes(KERNEL_NAMES[dom], n_loc, m_loc, k)
+        achieved = alg / (kavg[dom] * 1e-3) / 1e9
+        b_alg_job = n_total * 28 + (n_total * 12 + m_total * 12 + m_total * k * 16 + m_total * (4 * k + 24))
+        out = {
+            "metric": "target points/sec (k=%d detail transfer)" % k,
+            "value": value, "unit": "target points/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d-point source / %d targets / k=%d, uniform fp32 xyz in the unit cube, generator seed 0x%X"
+                                   % (args.workload, n_total, m_total, k, seed),
+                       "step": "grid build + target binning + k-NN + slab exchange/merge + mean blend, inputs resident in HBM",
+                       "parallelism": "slab%d" % world if world > 1 else "single"},
+            "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": alg, "avg_launch_ms": kavg[dom]},
+            "job_roofline": {"alg_bytes_per_step": b_alg_job, "achieved": b_alg_job / (ms_per_step * 1e-3) / 1e9 / world, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s per GPU", "frac": b_alg_job / (ms_per_step * 1e-3) / 1e9 / world / HBM_PEAK_GBS},
+            "kernels_ms": dict(zip(KERNEL_NAMES, [round(v, 4) for v in kavg])),
+            "phases_ms": {a: round(b / K, 4) for a, b in phase.items()},
+            "rank0": {"n_source": n_loc, "n_target": m_loc, "exchange": xstats},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(n_total, m_total, k, seed)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    pt.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,10 @@ typedef struct pt_stats_t {
   double cell_size;
   uint64_t n_cells;
   uint64_t device_bytes;    /* bytes currently allocated by the context */
+  /* per-kernel device times of the last build / query (HIP events on the launch stream), ms:
+   * [0] bbox reduce + readback, [1] pass-1 histogram, [2] pass-1 scatter, [3] pass-2 histogram + block scan,
+   * [4] pass-2 scatter, [5] finalize (cell sort), [6] target sort (all passes), [7] k-NN kernel */
+  double ms_kernel[8];
 } pt_stats_t;
 
 /* ---- context ------------------------------------------------------------------------ */

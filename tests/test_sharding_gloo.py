@@ -1,0 +1,54 @@
+"""CPU suite, part 3: the multi-GPU slab protocol (pt_amd.sharding) over torch.distributed/gloo with
+world_size 2 and 3.  The exchange code is the product's; the compute steps are the oracle's (no GPU here)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,case", [(2, "uniform"), (3, "uniform"), (2, "clustered"), (3, "tiny")])
+def test_slab_exchange_equals_global_knn(world, case):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PT_CASE=case, OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_sharding_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+    assert "RESULT" in outs[0]
+
+
+def test_slab_bounds_helpers():
+    import torch
+    import __graft_entry__ as g
+    g.load_package()
+    from pt_amd import sharding
+    b = sharding.uniform_slab_bounds(4)
+    assert b[0] == float("-inf") and b[-1] == float("inf") and b[1:4] == [0.25, 0.5, 0.75]
+    q = sharding.quantile_slab_bounds(torch.arange(1000.0), 4)
+    assert len(q) == 5 and abs(q[2] - 499.5) < 1.0
+    c = sharding.SingleComm()
+    assert c.world == 1 and c.max_int(7, "cpu") == 7
