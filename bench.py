@@ -56,7 +56,7 @@ def cpu_baseline(n_total, m_total, k, seed):
     from oracle import oracle as O
     O.build()
     ratio = max(1, n_total // max(m_total, 1))
-    ns = min(n_total, 4_000_000)
+    ns = min(n_total, 40_000_000)     # ~10-30 s of CPU work on the GPU box's host (the build is single-threaded)
     ms = max(1000, min(m_total, ns // ratio))
     src = O.synth_xyz(seed, 0, ns)
     tgt = O.synth_xyz(seed, 1, ms)
