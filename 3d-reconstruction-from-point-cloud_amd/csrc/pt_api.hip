@@ -113,11 +113,13 @@ int finish(pt_ctx* c) {
 }
 
 // carve the SortTables of one sort out of a single allocation
-int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks) {
+int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32_t npoints, size_t rec_size) {
   const size_t small = PT_MAXBINS + 8;
   const size_t words = small * 4 /*counts1,start1,cursor1,tile_first2*/ + 16 /*tile_first1, seg_start1*/ +
                        ((size_t)nblocks + 8) * 3 + ((size_t)nblocks / 2048 + 16);
-  RES(c, mem, words * sizeof(uint32_t));
+  const size_t nchunks = pt_sort_num_chunks(npoints, rec_size), nbins1 = nblocks / PT_MACRO_BLOCKS + 1;
+  const size_t chunk_words = nblocks > PT_MAXBINS ? (nchunks + 1) * nbins1 + (nchunks / 64 + 2) * nbins1 : 0;
+  RES(c, mem, (words + chunk_words + 16) * sizeof(uint32_t));
   uint32_t* p = (uint32_t*)mem.p;
   tb.counts1 = p; p += small;
   tb.start1 = p; p += small;
@@ -128,7 +130,9 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks) {
   tb.block_count = p; p += (size_t)nblocks + 8;
   tb.block_start = p; p += (size_t)nblocks + 8;
   tb.cursor2 = p; p += (size_t)nblocks + 8;
-  tb.scan_tmp = p;
+  tb.scan_tmp = p; p += (size_t)nblocks / 2048 + 16;
+  tb.chunk_hist = p; p += (nchunks + 1) * nbins1;
+  tb.chunk_gsum = p;
   tb.ev = nullptr;
   return PT_OK;
 }
@@ -192,7 +196,7 @@ int rebuild(pt_ctx* c) {
   RES(c, c->cell_start, (ncells + 1) * sizeof(uint32_t));
   RES(c, c->rec, std::max<size_t>(c->n, 1) * recsize(c->src_type));
   RES(c, c->rec_tmp, std::max<size_t>(c->n, 1) * recsize(c->src_type));
-  { int r = make_tables(c, c->stb_mem, c->stb, nblocks); if (r != PT_OK) return r; }
+  { int r = make_tables(c, c->stb_mem, c->stb, nblocks, (uint32_t)c->n, recsize(c->src_type)); if (r != PT_OK) return r; }
   c->stb.ev = c->sev;
   if (c->src_type == PT_F32) run_source_sort<float, RecF>(c); else run_source_sort<double, RecD>(c);
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -242,7 +246,7 @@ int query_resident(pt_ctx* c, int k, const double* bound2_dev, uint32_t* idx_dev
   const uint32_t m = (uint32_t)c->m;
   RES(c, c->trec, std::max<size_t>(m, 1) * recsize(c->tgt_type));
   RES(c, c->trec_tmp, std::max<size_t>(m, 1) * recsize(c->tgt_type));
-  { int r = make_tables(c, c->ttb_mem, c->ttb, (uint32_t)c->gp.nblocks); if (r != PT_OK) return r; }
+  { int r = make_tables(c, c->ttb_mem, c->ttb, (uint32_t)c->gp.nblocks, m, recsize(c->tgt_type)); if (r != PT_OK) return r; }
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (c->tgt_type == PT_F32) {
     const float* x = (const float*)c->t_xyz.p;

@@ -304,46 +304,182 @@ __global__ __launch_bounds__(WG) void scatter_kernel(Loader in, typename Loader:
   }
 }
 
-// ---- finalize: counting sort of one 8x8x8-cell block by local cell, in LDS -------------------------
-template <class Rec>
-__global__ __launch_bounds__(WG) void finalize_kernel(const Rec* __restrict__ in, Rec* __restrict__ out, GridParams gp,
-                                                      const uint32_t* __restrict__ block_start, uint32_t* cell_start) {
-  __shared__ uint32_t cnt[PT_BLOCK_CELLS];
+// ---- pass 1 without atomics: fixed chunks of tiles, per-chunk histograms, column scan, chunk-local cursors ----
+// (with only <= 1024 bins, a global cursor per bin would be hit by every tile of the cloud: at 1e9 points that
+//  serialises ~5e5 reservations per address.  Chunks make the placement deterministic and contention-free.)
+template <class Loader, int ITEMS>
+__global__ __launch_bounds__(WG) void hist_chunk_kernel(Loader in, GridParams gp, BinSpec bs, uint32_t n, int chunk_tiles,
+                                                        uint32_t* __restrict__ chunk_hist) {
+  __shared__ uint32_t hist[PT_MAXBINS];
+  for (int b = threadIdx.x; b < bs.nbins; b += WG) hist[b] = 0;
+  __syncthreads();
+  const uint64_t span = (uint64_t)chunk_tiles * (WG * ITEMS);
+  const uint64_t base = (uint64_t)blockIdx.x * span;
+  const uint32_t end = (uint32_t)min((uint64_t)n, base + span);
+  for (uint32_t i = (uint32_t)base + threadIdx.x; i < end; i += WG) atomicAdd(&hist[local_bin(bs, block_of_rec(gp, in.load(i)))], 1u);
+  __syncthreads();
+  for (int b = threadIdx.x; b < bs.nbins; b += WG) chunk_hist[(size_t)blockIdx.x * bs.nbins + b] = hist[b];
+}
+constexpr int COL_GROUP = 64;   // chunk rows per column-scan group
+__global__ __launch_bounds__(WG) void colsum_kernel(const uint32_t* __restrict__ mat, int nrows, int nbins, uint32_t* __restrict__ gsum) {
+  const int r0 = blockIdx.x * COL_GROUP, r1 = min(nrows, r0 + COL_GROUP);
+  for (int b = threadIdx.x; b < nbins; b += WG) {
+    uint32_t sacc = 0;
+    for (int r = r0; r < r1; ++r) sacc += mat[(size_t)r * nbins + b];
+    gsum[(size_t)blockIdx.x * nbins + b] = sacc;
+  }
+}
+__global__ __launch_bounds__(WG) void colscan_kernel(uint32_t* __restrict__ gsum, int ngroups, int nbins, uint32_t* __restrict__ totals) {
+  for (int b = threadIdx.x; b < nbins; b += WG) {
+    uint32_t run = 0;
+    for (int g = 0; g < ngroups; ++g) { const uint32_t t = gsum[(size_t)g * nbins + b]; gsum[(size_t)g * nbins + b] = run; run += t; }
+    totals[b] = run;
+  }
+}
+__global__ __launch_bounds__(WG) void colapply_kernel(uint32_t* __restrict__ mat, int nrows, int nbins, const uint32_t* __restrict__ gsum,
+                                                      const uint32_t* __restrict__ bin_start) {
+  const int r0 = blockIdx.x * COL_GROUP, r1 = min(nrows, r0 + COL_GROUP);
+  for (int b = threadIdx.x; b < nbins; b += WG) {
+    uint32_t run = bin_start[b] + gsum[(size_t)blockIdx.x * nbins + b];
+    for (int r = r0; r < r1; ++r) { const uint32_t t = mat[(size_t)r * nbins + b]; mat[(size_t)r * nbins + b] = run; run += t; }
+  }
+}
+template <class Loader, int ITEMS>
+__global__ __launch_bounds__(WG) void scatter_chunk_kernel(Loader in, typename Loader::Rec* __restrict__ out, GridParams gp, BinSpec bs, uint32_t n,
+                                                           int chunk_tiles, const uint32_t* __restrict__ chunk_base) {
+  using Rec = typename Loader::Rec;
+  constexpr uint32_t TILE = WG * ITEMS;
+  constexpr int BPT = PT_MAXBINS / WG;
+  __shared__ uint32_t cursor[PT_MAXBINS];         // next free global slot of every bin, for this chunk
+  __shared__ uint32_t binA[PT_MAXBINS];
+  __shared__ uint32_t binB[PT_MAXBINS];
   __shared__ uint32_t wsum[4];
+  __shared__ Rec stage[TILE];
+  for (int b = threadIdx.x; b < PT_MAXBINS; b += WG) cursor[b] = b < bs.nbins ? chunk_base[(size_t)blockIdx.x * bs.nbins + b] : 0u;
+  for (int t = 0; t < chunk_tiles; ++t) {
+    const uint64_t s64 = ((uint64_t)blockIdx.x * chunk_tiles + t) * TILE;
+    if (s64 >= n) break;
+    const uint32_t s = (uint32_t)s64, e = (uint32_t)min((uint64_t)n, s64 + TILE);
+    for (int b = threadIdx.x; b < PT_MAXBINS; b += WG) binA[b] = 0;
+    __syncthreads();
+    Rec r[ITEMS];
+    uint32_t lb[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const uint32_t i = s + j * WG + threadIdx.x;
+      if (i < e) {
+        r[j] = in.load(i);
+        lb[j] = local_bin(bs, block_of_rec(gp, r[j]));
+        rank[j] = atomicAdd(&binA[lb[j]], 1u);
+      }
+    }
+    __syncthreads();
+    {
+      uint32_t c[BPT], sum = 0;
+#pragma unroll
+      for (int i = 0; i < BPT; ++i) { c[i] = binA[threadIdx.x * BPT + i]; sum += c[i]; }
+      uint32_t tot;
+      uint32_t ex = block_excl_scan(sum, wsum, tot);
+#pragma unroll
+      for (int i = 0; i < BPT; ++i) {
+        const int b = threadIdx.x * BPT + i;
+        binA[b] = ex;
+        binB[b] = cursor[b] - ex;
+        cursor[b] += c[i];               // one thread owns each bin: no race
+        ex += c[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const uint32_t i = s + j * WG + threadIdx.x;
+      if (i < e) stage[binA[lb[j]] + rank[j]] = r[j];
+    }
+    __syncthreads();
+    const uint32_t cnt = e - s;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const uint32_t slot = j * WG + threadIdx.x;
+      if (slot < cnt) {
+        const Rec v = stage[slot];
+        out[binB[local_bin(bs, block_of_rec(gp, v))] + slot] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- finalize: counting sort of one 8x8x8-cell block by local cell, in LDS -------------------------
+constexpr int FWG = 512;        // finalize workgroup: one thread per local cell in the scan
+constexpr int FITEMS = 12;      // records a thread keeps in registers: blocks up to 6144 points are read once
+template <class Rec>
+__global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ in, Rec* __restrict__ out, GridParams gp,
+                                                       const uint32_t* __restrict__ block_start, uint32_t* cell_start) {
+  __shared__ uint32_t cnt[PT_BLOCK_CELLS];
+  __shared__ uint32_t wsum[FWG / 64];
   const uint32_t b = blockIdx.x;
   const uint32_t s = block_start[b], e = block_start[b + 1];
   if (s == e) {   // empty block: only the table
     if (cell_start) {
       cell_start[b * PT_BLOCK_CELLS + threadIdx.x] = s;
-      cell_start[b * PT_BLOCK_CELLS + WG + threadIdx.x] = s;
       if (b == gridDim.x - 1 && threadIdx.x == 0) cell_start[(b + 1) * PT_BLOCK_CELLS] = e;
     }
     return;
   }
-  cnt[threadIdx.x] = 0; cnt[WG + threadIdx.x] = 0;
+  cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (uint32_t i = s + threadIdx.x; i < e; i += WG) {
-    int cx, cy, cz;
-    pt_cell_of(gp, in[i], cx, cy, cz);
-    atomicAdd(&cnt[pt_local_cell(cx, cy, cz)], 1u);
+  const bool in_regs = (e - s) <= (uint32_t)(FWG * FITEMS);
+  Rec r[FITEMS];
+  uint32_t lc[FITEMS];
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < FITEMS; ++j) {
+      const uint32_t i = s + j * FWG + threadIdx.x;
+      if (i < e) {
+        r[j] = in[i];
+        int cx, cy, cz;
+        pt_cell_of(gp, r[j], cx, cy, cz);
+        lc[j] = pt_local_cell(cx, cy, cz);
+        atomicAdd(&cnt[lc[j]], 1u);
+      }
+    }
+  } else {
+    for (uint32_t i = s + threadIdx.x; i < e; i += FWG) {
+      int cx, cy, cz;
+      pt_cell_of(gp, in[i], cx, cy, cz);
+      atomicAdd(&cnt[pt_local_cell(cx, cy, cz)], 1u);
+    }
   }
   __syncthreads();
-  const uint32_t c0 = cnt[2 * threadIdx.x], c1 = cnt[2 * threadIdx.x + 1];
-  uint32_t tot;
-  const uint32_t ex = block_excl_scan(c0 + c1, wsum, tot);
+  // exclusive scan of the 512 cell counts, one per thread
+  const uint32_t c0 = cnt[threadIdx.x];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t incl = wave_incl_scan(c0);
+  if (lane == 63) wsum[w] = incl;
   __syncthreads();
-  cnt[2 * threadIdx.x] = ex; cnt[2 * threadIdx.x + 1] = ex + c0;     // cursors, relative to s
+  uint32_t off = 0;
+#pragma unroll
+  for (int i = 0; i < FWG / 64; ++i) if (i < w) off += wsum[i];
+  const uint32_t ex = off + incl - c0;
+  cnt[threadIdx.x] = ex;                      // cursor, relative to s
   if (cell_start) {
-    cell_start[b * PT_BLOCK_CELLS + 2 * threadIdx.x] = s + ex;
-    cell_start[b * PT_BLOCK_CELLS + 2 * threadIdx.x + 1] = s + ex + c0;
+    cell_start[b * PT_BLOCK_CELLS + threadIdx.x] = s + ex;
     if (b == gridDim.x - 1 && threadIdx.x == 0) cell_start[(b + 1) * PT_BLOCK_CELLS] = e;
   }
   __syncthreads();
-  for (uint32_t i = s + threadIdx.x; i < e; i += WG) {   // second read is served by L2
-    const Rec v = in[i];
-    int cx, cy, cz;
-    pt_cell_of(gp, v, cx, cy, cz);
-    out[s + atomicAdd(&cnt[pt_local_cell(cx, cy, cz)], 1u)] = v;
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < FITEMS; ++j) {
+      const uint32_t i = s + j * FWG + threadIdx.x;
+      if (i < e) out[s + atomicAdd(&cnt[lc[j]], 1u)] = r[j];
+    }
+  } else {
+    for (uint32_t i = s + threadIdx.x; i < e; i += FWG) {   // oversized block: second read (mostly L2)
+      const Rec v = in[i];
+      int cx, cy, cz;
+      pt_cell_of(gp, v, cx, cy, cz);
+      out[s + atomicAdd(&cnt[pt_local_cell(cx, cy, cz)], 1u)] = v;
+    }
   }
 }
 
@@ -353,6 +489,17 @@ template <class Rec> constexpr int items_for() { return sizeof(Rec) == 16 ? 8 : 
 
 // =================================================================================================
 int pt_sort_tile_points(size_t rec_size) { return WG * (rec_size == 16 ? 8 : 4); }
+// tiles per pass-1 chunk: enough chunks to fill the chip, few enough that the chunk-histogram table stays small
+int pt_sort_chunk_tiles(uint32_t n, size_t rec_size) {
+  const uint32_t tile = (uint32_t)pt_sort_tile_points(rec_size);
+  const uint32_t ntiles = (n + tile - 1) / tile;
+  return (int)std::max<uint32_t>(1, std::min<uint32_t>(32, ntiles / 4096));
+}
+uint32_t pt_sort_num_chunks(uint32_t n, size_t rec_size) {
+  const uint32_t tile = (uint32_t)pt_sort_tile_points(rec_size);
+  const uint32_t ntiles = (n + tile - 1) / tile, ct = (uint32_t)pt_sort_chunk_tiles(n, rec_size);
+  return (ntiles + ct - 1) / ct;
+}
 
 void pt_launch_bbox_init(uint64_t* out6, hipStream_t s) { hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, s, out6); }
 template <class T>
@@ -410,24 +557,29 @@ void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* 
                          tb.tile_first1, 1, tb.cursor2);
     mark(4);
     blocked = tmp;
-    hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(WG), 0, s, blocked, out_final, gp, tb.block_start, cell_start);
+    hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, blocked, out_final, gp, tb.block_start, cell_start);
     mark(5);
     return;
   }
   // two levels: planar -> out_final (by macro block) -> tmp (by block) -> out_final (by cell)
   const BinSpec b1{0, 9, (int)nmacro};
   const BinSpec b2{1, 9, PT_MACRO_BLOCKS};
+  const int chunk_tiles = pt_sort_chunk_tiles(n, sizeof(Rec));
+  const uint32_t nchunks = n ? (ntiles + chunk_tiles - 1) / chunk_tiles : 0;
+  const uint32_t ngroups = (nchunks + COL_GROUP - 1) / COL_GROUP;
   (void)hipMemsetAsync(tb.counts1, 0, sizeof(uint32_t) * (PT_MAXBINS + 1), s);
   if (n) {
-    const int tpw = 8;
-    hipLaunchKernelGGL((hist_kernel<PlanarLoader<T>, ITEMS>), dim3((ntiles + tpw - 1) / tpw), dim3(WG), 0, s, pl, gp, b1,
-                       tb.seg_start1, tb.tile_first1, 1, tb.counts1, tpw);
+    hipLaunchKernelGGL((hist_chunk_kernel<PlanarLoader<T>, ITEMS>), dim3(nchunks), dim3(WG), 0, s, pl, gp, b1, n, chunk_tiles, tb.chunk_hist);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ngroups), dim3(WG), 0, s, tb.chunk_hist, (int)nchunks, (int)nmacro, tb.chunk_gsum);
+    hipLaunchKernelGGL(colscan_kernel, dim3(1), dim3(WG), 0, s, tb.chunk_gsum, (int)ngroups, (int)nmacro, tb.counts1);
   }
   hipLaunchKernelGGL(seg_setup_kernel, dim3(1), dim3(WG), 0, s, tb.counts1, (int)nmacro, n, TILE, tb.start1, tb.cursor1, tb.tile_first2);
   mark(1);
-  if (n)
-    hipLaunchKernelGGL((scatter_kernel<PlanarLoader<T>, ITEMS>), dim3(ntiles), dim3(WG), 0, s, pl, out_final, gp, b1, tb.seg_start1,
-                       tb.tile_first1, 1, tb.cursor1);
+  if (n) {
+    hipLaunchKernelGGL(colapply_kernel, dim3(ngroups), dim3(WG), 0, s, tb.chunk_hist, (int)nchunks, (int)nmacro, tb.chunk_gsum, tb.start1);
+    hipLaunchKernelGGL((scatter_chunk_kernel<PlanarLoader<T>, ITEMS>), dim3(nchunks), dim3(WG), 0, s, pl, out_final, gp, b1, n, chunk_tiles,
+                       tb.chunk_hist);
+  }
   mark(2);
   RecLoader<Rec> rl{out_final};
   const uint32_t ntiles2 = ntiles + nmacro;   // upper bound: every segment adds at most one partial tile
@@ -443,7 +595,7 @@ void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* 
     hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS>), dim3(ntiles2), dim3(WG), 0, s, rl, tmp, gp, b2, tb.start1, tb.tile_first2,
                        (int)nmacro, tb.cursor2);
   mark(4);
-  hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(WG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start);
+  hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start);
   mark(5);
 }
 template void pt_launch_grid_sort<float, RecF>(const GridParams&, const float*, const float*, const float*, const uint32_t*, uint32_t, RecF*,

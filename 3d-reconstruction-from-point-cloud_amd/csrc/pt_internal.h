@@ -16,6 +16,8 @@ struct SortTables {
   uint32_t* block_start; // [nblocks+1]
   uint32_t* cursor2;     // [nblocks]
   uint32_t* scan_tmp;    // [>= nblocks/2048 + 2]
+  uint32_t* chunk_hist;  // [nchunks][nbins1]   per-chunk pass-1 histograms, then per-chunk bin cursors
+  uint32_t* chunk_gsum;  // [ceil(nchunks/64)][nbins1]
   hipEvent_t* ev;        // optional [6]: start, after hist1, scatter1, hist2+scan, scatter2, finalize (null = no timing)
 };
 
@@ -32,6 +34,8 @@ template <class T, class Rec>
 void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* z, const uint32_t* gidx, uint32_t n,
                          Rec* out_final, Rec* tmp, uint32_t* cell_start, const SortTables& tb, hipStream_t s);
 int pt_sort_tile_points(size_t rec_size);
+int pt_sort_chunk_tiles(uint32_t n, size_t rec_size);
+uint32_t pt_sort_num_chunks(uint32_t n, size_t rec_size);
 
 // generic exclusive scan of u32 (n <= 2048*2048*... see pt_grid.hip); out may alias in
 void pt_launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* tmp, hipStream_t s);
