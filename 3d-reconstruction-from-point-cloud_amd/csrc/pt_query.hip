@@ -9,11 +9,17 @@
 // boxes; ring termination is the same bound applied to the faces of the box already scanned.
 //
 // Mapping onto the wave: 8 lanes per target, 8 targets per wave64, 32 per 256-thread workgroup.
-//   - a target's candidate cells are x-runs of cells (contiguous in the sorted records), so the 8 lanes of a
-//     group read 8 consecutive 16-B records = one 128-B line per step;
+//   - ring 1 (the 3x3x3 cells around the target) is 9 x-rows of 3 cells.  The group's lanes look the rows'
+//     cell ranges up in parallel (one latency for all of them), then the rows are processed centre first;
+//     a row's surviving cells are flattened into one index space so that the 8 lanes always read 8 consecutive
+//     candidates (128-B lines of 16-B records), a whole row's records are requested in one batch, and the next
+//     row's batch is already in flight while the current one is ranked;
 //   - the running top-k lives in registers, distributed over the group's lanes (lane L holds ranks
 //     [L*KPL, (L+1)*KPL), KPL = ceil(k/8)), ordered by the total order (d2, original index);
-//   - a candidate is offered with one group ballot; an insertion is a one-position shift across lanes.
+//   - a candidate is offered with one group ballot; an insertion is a one-position shift across lanes done
+//     with DPP row operations (no LDS traffic);
+//   - rings >= 2 (needed by the few targets whose k-th neighbour is farther than one cell) use a plain
+//     row-by-row walk.
 // Control flow is uniform inside a group (all 8 lanes take every branch together), so cross-lane operations
 // never see an inactive partner; different groups of a wave diverge freely.
 #include "pt_internal.h"
@@ -34,37 +40,60 @@ __device__ inline double dist2(const double (&q)[3], const Rec& r) {
   return (dx * dx + dy * dy) + dz * dz;     // reference src/Distance.h:10, left to right, unfused
 }
 
-template <class Rec, int KPL>
-struct GroupSearch {
-  const GridParams& gp;
-  const Rec* __restrict__ src;
-  const uint32_t* __restrict__ cs;
-  double q[3], u[3];
-  int c[3];
-  double ld[KPL];          // this lane's slice of the sorted top list
+// ---- DPP helpers: data movement inside the 8-lane group without touching LDS ---------------------------------
+template <int CTRL>
+__device__ inline uint32_t dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ inline double dpp_f64(double v) {
+  const uint32_t lo = dpp_u32<CTRL>((uint32_t)__double2loint(v)), hi = dpp_u32<CTRL>((uint32_t)__double2hiint(v));
+  return __hiloint2double((int)hi, (int)lo);
+}
+constexpr int DPP_SHR1 = 0x111;          // row_shr:1      lane i <- lane i-1
+constexpr int DPP_QUAD3 = 0xFF;          // quad_perm [3,3,3,3]
+constexpr int DPP_HMIRROR = 0x141;       // row_half_mirror: lane i <- lane 7-i of the same 8 lanes
+// broadcast lane 7 (resp. lane 0) of every 8-lane group to the whole group; L = lane index inside the group
+__device__ inline uint32_t bcast7(uint32_t v, int L) { const uint32_t a = dpp_u32<DPP_QUAD3>(v), b = dpp_u32<DPP_HMIRROR>(a); return L < 4 ? b : a; }
+__device__ inline double bcast7(double v, int L) { const double a = dpp_f64<DPP_QUAD3>(v), b = dpp_f64<DPP_HMIRROR>(a); return L < 4 ? b : a; }
+
+// ---- the running top list of one target, spread over the 8 lanes of its group ------------------------------------
+template <int KPL>
+struct TopList {
+  double ld[KPL];
   uint32_t li[KPL];
-  double lim_d, bnd_d;     // acceptance limit = min(k-th entry, caller's bound); both with index NOIDX when unset
+  double lim_d, bnd_d;     // acceptance limit = min(entry of rank k-1, caller's bound); index NOIDX when it is a bare bound
   uint32_t lim_i;
-  double h2;
-  int L, gshift, hl, hr;
+  int L, hl, hr;
+  uint32_t notfirst;       // 0 for lane 0 of the group, 1 otherwise
+  bool fullk;              // k == 8*KPL: the rank k-1 entry is the last entry of lane 7
 
-  __device__ GroupSearch(const GridParams& g, const Rec* s, const uint32_t* cell_start) : gp(g), src(s), cs(cell_start) {}
-
-  // distance (cell units, >= 0) from the target to the cell interval [lo, hi] along axis a, minus the slack
-  __device__ double gap(int a, int lo, int hi) const {
-    const double g = fmax((double)lo - u[a], u[a] - (double)(hi + 1)) - PT_CELL_EPS;
-    return fmax(g, 0.0);
+  __device__ void init(int lane_in_group, int k, double bound) {
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) { ld[j] = INFINITY; li[j] = PT_NOIDX_U; }
+    L = lane_in_group;
+    notfirst = lane_in_group != 0 ? 1u : 0u;
+    hl = (k - 1) / KPL;
+    hr = (k - 1) % KPL;
+    fullk = (k == GL * KPL);
+    bnd_d = bound;
+    lim_d = bound;
+    lim_i = PT_NOIDX_U;
   }
+  __device__ bool accepts(double d, uint32_t i) const { return key_lt(d, i, lim_d, lim_i); }
 
+  // insert (xd, xi), known by every lane of the group, into the sorted list; the last entry falls off
   __device__ void insert(double xd, uint32_t xi) {
     bool cj[KPL];
 #pragma unroll
     for (int j = 0; j < KPL; ++j) cj[j] = key_lt(xd, xi, ld[j], li[j]);
     // the lane below hands over its last entry if the new key sorts before it
-    const double pd = __shfl_up(ld[KPL - 1], 1, GL);
-    const uint32_t pi = __shfl_up(li[KPL - 1], 1, GL);
-    int pc = __shfl_up((int)cj[KPL - 1], 1, GL);
-    if (L == 0) pc = 0;
+    const double pd = dpp_f64<DPP_SHR1>(ld[KPL - 1]);
+    const uint32_t pi = dpp_u32<DPP_SHR1>(li[KPL - 1]);
+    // (every cross-lane move is executed by ALL lanes of the group: never under a lane-dependent branch, or the
+    //  source lane may be masked off; lane 0's incoming value is discarded arithmetically instead)
+    const uint32_t pcv = dpp_u32<DPP_SHR1>(cj[KPL - 1] ? 1u : 0u) & notfirst;
+    const bool pc = pcv != 0u;
 #pragma unroll
     for (int j = KPL - 1; j >= 1; --j) {
       if (cj[j - 1]) { ld[j] = ld[j - 1]; li[j] = li[j - 1]; }
@@ -73,129 +102,247 @@ struct GroupSearch {
     if (pc) { ld[0] = pd; li[0] = pi; }
     else if (cj[0]) { ld[0] = xd; li[0] = xi; }
     // new acceptance limit: the entry of rank k-1, unless the caller's bound is tighter
-    double kd = ld[0];
-    uint32_t ki = li[0];
+    double kd;
+    uint32_t ki;
+    if (fullk) {
+      kd = bcast7(ld[KPL - 1], L);
+      ki = bcast7(li[KPL - 1], L);
+    } else {
+      kd = ld[0];
+      ki = li[0];
 #pragma unroll
-    for (int j = 1; j < KPL; ++j) if (hr == j) { kd = ld[j]; ki = li[j]; }
-    kd = __shfl(kd, hl, GL);
-    ki = __shfl(ki, hl, GL);
+      for (int j = 1; j < KPL; ++j) if (hr == j) { kd = ld[j]; ki = li[j]; }
+      kd = __shfl(kd, hl, GL);
+      ki = __shfl(ki, hl, GL);
+    }
     if (key_lt(kd, ki, bnd_d, PT_NOIDX_U)) { lim_d = kd; lim_i = ki; }
     else { lim_d = bnd_d; lim_i = PT_NOIDX_U; }
   }
 
-  // offer the records [s, e) of the sorted cloud
-  __device__ void scan_range(uint32_t s, uint32_t e) {
-    for (uint32_t base = s; base < e; base += GL) {
-      const uint32_t p = base + L;
-      double d = INFINITY;
-      uint32_t id = PT_NOIDX_U;
-      if (p < e) {
-        const Rec r = src[p];
-        d = dist2(q, r);
-        id = r.id;
-      }
-      const bool pass = key_lt(d, id, lim_d, lim_i);
-      uint32_t mask = (uint32_t)(__ballot(pass) >> gshift) & 0xFFu;
-      while (mask) {
-        const int t = __ffs(mask) - 1;
-        mask &= mask - 1;
-        const double xd = __shfl(d, t, GL);
-        const uint32_t xi = __shfl(id, t, GL);
-        if (key_lt(xd, xi, lim_d, lim_i)) insert(xd, xi);   // re-test: the limit may have tightened this step
-      }
-    }
-  }
-
-  // cells [xa, xb] x {y} x {z} (inside the grid); prunes by the box lower bound, then walks the run block by block
-  __device__ void scan_row(int xa, int xb, int y, int z) {
-    const double gy = gap(1, y, y), gz = gap(2, z, z);
-    const double s2 = gy * gy + gz * gz;
-    if (s2 * h2 > lim_d) return;
-    while (xa < xb) { const double g = gap(0, xa, xa); if ((g * g + s2) * h2 > lim_d) ++xa; else break; }
-    while (xb > xa) { const double g = gap(0, xb, xb); if ((g * g + s2) * h2 > lim_d) --xb; else break; }
-    { const double g = gap(0, xa, xb); if ((g * g + s2) * h2 > lim_d) return; }
-    for (int bx = xa >> 3; bx <= (xb >> 3); ++bx) {
-      const int pa = max(xa, bx << 3), pb = min(xb, (bx << 3) + 7);
-      const uint32_t key = (pt_block_id(gp.mdim, pa, y, z) << 9) + pt_local_cell(pa, y, z);
-      const uint32_t s = cs[key], e = cs[key + (uint32_t)(pb - pa) + 1u];
-      scan_range(s, e);
+  // offer one candidate per lane (d = +inf / id = NOIDX for lanes without one)
+  __device__ void offer(double d, uint32_t id, int gshift) {
+    const bool pass = accepts(d, id);
+    uint32_t mask = (uint32_t)(__ballot(pass) >> gshift) & 0xFFu;
+    while (mask) {
+      const int t = __ffs(mask) - 1;
+      mask &= mask - 1;
+      const double xd = __shfl(d, t, GL);
+      const uint32_t xi = __shfl(id, t, GL);
+      if (accepts(xd, xi)) insert(xd, xi);   // re-test: the limit may have tightened within this step
     }
   }
 };
 
+// geometry of one target relative to the grid
+struct TargetGeom {
+  double q[3], u[3];
+  int c[3];
+  double h2;
+  // distance (cell units, >= 0) from the target to the cell interval [lo, hi] along axis a, minus the slack
+  __device__ double gap(int a, int lo, int hi) const {
+    const double g = fmax((double)lo - u[a], u[a] - (double)(hi + 1)) - PT_CELL_EPS;
+    return fmax(g, 0.0);
+  }
+};
+
+__device__ inline uint32_t cell_key(const GridParams& gp, int x, int y, int z) {
+  return (pt_block_id(gp.mdim, x, y, z) << 9) + pt_local_cell(x, y, z);
+}
+
+// generic walk of cells [xa, xb] x {y} x {z} (inside the grid): prune by the box lower bound, then scan block by block
 template <class Rec, int KPL>
-__global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __restrict__ src, const uint32_t* __restrict__ cell_start,
+__device__ void scan_row_generic(const GridParams& gp, const Rec* __restrict__ src, const uint32_t* __restrict__ cs, const TargetGeom& T,
+                                 TopList<KPL>& top, int gshift, int xa, int xb, int y, int z) {
+  const double gy = T.gap(1, y, y), gz = T.gap(2, z, z);
+  const double s2 = gy * gy + gz * gz;
+  if (s2 * T.h2 > top.lim_d) return;
+  while (xa < xb) { const double g = T.gap(0, xa, xa); if ((g * g + s2) * T.h2 > top.lim_d) ++xa; else break; }
+  while (xb > xa) { const double g = T.gap(0, xb, xb); if ((g * g + s2) * T.h2 > top.lim_d) --xb; else break; }
+  { const double g = T.gap(0, xa, xb); if ((g * g + s2) * T.h2 > top.lim_d) return; }
+  for (int bx = xa >> 3; bx <= (xb >> 3); ++bx) {
+    const int pa = max(xa, bx << 3), pb = min(xb, (bx << 3) + 7);
+    const uint32_t key = cell_key(gp, pa, y, z);
+    const uint32_t s = cs[key], e = cs[key + (uint32_t)(pb - pa) + 1u];
+    for (uint32_t base = s; base < e; base += GL) {
+      const uint32_t p = base + top.L;
+      double d = INFINITY;
+      uint32_t id = PT_NOIDX_U;
+      if (p < e) { const Rec r = src[p]; d = dist2(T.q, r); id = r.id; }
+      top.offer(d, id, gshift);
+    }
+  }
+}
+
+// (dy,dz)+1 of the 9 rows of ring 1, packed 2 bits each, centre row first, then faces, then edges:
+// dy = 0,-1,1,0,0,-1,1,-1,1 ; dz = 0,0,0,-1,1,-1,-1,1,1
+constexpr uint32_t ROW_OY = 139617u, ROW_OZ = 164373u;
+__device__ inline int row_dy(int r) { return (int)((ROW_OY >> (2 * r)) & 3u) - 1; }
+__device__ inline int row_dz(int r) { return (int)((ROW_OZ >> (2 * r)) & 3u) - 1; }
+
+template <class Rec> struct Batch { static constexpr int N = sizeof(Rec) == 16 ? 4 : 2; };   // steps requested at once
+
+// the cells of one row that survive pruning, flattened: virtual position v -> record index
+struct RowPlan {
+  uint32_t a0, a1, a2;     // first record of the three cells
+  uint32_t n0, n01, T;     // prefix sums of the surviving cells' sizes: n0, n0+n1, n0+n1+n2
+  __device__ uint32_t addr(uint32_t v) const { return v < n0 ? a0 + v : (v < n01 ? a1 + (v - n0) : a2 + (v - n01)); }
+};
+
+template <class Rec, int KPL>
+__global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __restrict__ src, const uint32_t* __restrict__ cs,
                                                  const Rec* __restrict__ tgt, uint32_t m, int k, const double* __restrict__ bound2,
                                                  uint32_t* __restrict__ out_idx, double* __restrict__ out_d2) {
+  constexpr int NB = Batch<Rec>::N;
   const uint32_t gid = (blockIdx.x * WG + threadIdx.x) / GL;
   if (gid >= m) return;                       // whole groups leave together
-  GroupSearch<Rec, KPL> S(gp, src, cell_start);
-  S.L = threadIdx.x & (GL - 1);
-  S.gshift = (threadIdx.x & 63) & ~(GL - 1);
-  S.hl = (k - 1) / KPL;
-  S.hr = (k - 1) % KPL;
-  S.h2 = gp.h * gp.h;
-  const Rec T = tgt[gid];
-  S.q[0] = (double)T.x; S.q[1] = (double)T.y; S.q[2] = (double)T.z;
+  const int L = threadIdx.x & (GL - 1);
+  const int gshift = (threadIdx.x & 63) & ~(GL - 1);
+  const Rec tr = tgt[gid];
+  TargetGeom T;
+  T.q[0] = (double)tr.x; T.q[1] = (double)tr.y; T.q[2] = (double)tr.z;
+  T.h2 = gp.h * gp.h;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    S.u[a] = (S.q[a] - gp.bbmin[a]) * gp.inv_h;
-    S.c[a] = (int)fmin(fmax(S.u[a], 0.0), (double)(gp.dim[a] - 1));
+    T.u[a] = (T.q[a] - gp.bbmin[a]) * gp.inv_h;
+    T.c[a] = (int)fmin(fmax(T.u[a], 0.0), (double)(gp.dim[a] - 1));
   }
-#pragma unroll
-  for (int j = 0; j < KPL; ++j) { S.ld[j] = INFINITY; S.li[j] = PT_NOIDX_U; }
-  S.bnd_d = bound2 ? bound2[T.id] : INFINITY;
-  S.lim_d = S.bnd_d;
-  S.lim_i = PT_NOIDX_U;
+  TopList<KPL> top;
+  top.init(L, k, bound2 ? bound2[tr.id] : INFINITY);
+  const int c0 = T.c[0], c1 = T.c[1], c2 = T.c[2];
 
-  const int c0 = S.c[0], c1 = S.c[1], c2 = S.c[2];
-  for (int r = 1;; ++r) {
-    const int x0 = max(c0 - r, 0), x1 = min(c0 + r, gp.dim[0] - 1);
-    const int y0 = max(c1 - r, 0), y1 = min(c1 + r, gp.dim[1] - 1);
-    const int z0 = max(c2 - r, 0), z1 = min(c2 + r, gp.dim[2] - 1);
-    if (r == 1) {
-      // the 3x3x3 box, centre row first so that the limit tightens before the outer rows are tested
-      // (dy,dz)+1 packed 2 bits each: dy = 0,-1,1,0,0,-1,1,-1,1 ; dz = 0,0,0,-1,1,-1,-1,1,1
-      constexpr uint32_t OY = 139617u, OZ = 164373u;
-#pragma unroll 1
-      for (int i = 0; i < 9; ++i) {
-        const int y = c1 + (int)((OY >> (2 * i)) & 3u) - 1, z = c2 + (int)((OZ >> (2 * i)) & 3u) - 1;
-        if (y >= y0 && y <= y1 && z >= z0 && z <= z1) S.scan_row(x0, x1, y, z);
-      }
-    } else {
-      // the shell box(r) \ box(r-1)
-      for (int z = z0; z <= z1; ++z)
-        for (int y = y0; y <= y1; ++y) {
-          const bool shell = (z == c2 - r) || (z == c2 + r) || (y == c1 - r) || (y == c1 + r);
-          if (shell) S.scan_row(x0, x1, y, z);
-          else {
-            if (c0 - r >= 0) S.scan_row(c0 - r, c0 - r, y, z);
-            if (c0 + r <= gp.dim[0] - 1) S.scan_row(c0 + r, c0 + r, y, z);
-          }
+  // ---- ring 1, phase A: cell ranges of the 9 rows.  Every lane looks up the centre row (row 0); lane L also
+  //      looks up row L+1.  12 independent loads per lane, one memory latency for the whole neighbourhood.
+  uint32_t cS[3], cE[3], mS[3], mE[3];          // centre row / my row: [start, end) of cells x = c0-1, c0, c0+1
+  {
+    const int my = L + 1;
+    const int y = c1 + row_dy(my), z = c2 + row_dz(my);
+    const bool rowok = y >= 0 && y < gp.dim[1] && z >= 0 && z < gp.dim[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int x = c0 - 1 + j;
+      const bool xok = x >= 0 && x < gp.dim[0];
+      cS[j] = cE[j] = mS[j] = mE[j] = 0;
+      if (xok) {
+        const uint32_t kc = cell_key(gp, x, c1, c2);
+        cS[j] = cs[kc]; cE[j] = cs[kc + 1];
+        if (rowok) {
+          const uint32_t km = cell_key(gp, x, y, z);
+          mS[j] = cs[km]; mE[j] = cs[km + 1];
         }
+      }
     }
-    // stop when the box covers the grid, or when nothing outside it can beat the limit:
+  }
+
+  // plan of row r under the current limit: which cells survive, where their records are
+  auto make_plan = [&](int r) -> RowPlan {
+    RowPlan P;
+    P.a0 = P.a1 = P.a2 = 0; P.n0 = P.n01 = P.T = 0;
+    const int y = c1 + row_dy(r), z = c2 + row_dz(r);
+    if (y < 0 || y >= gp.dim[1] || z < 0 || z >= gp.dim[2]) return P;
+    const double gy = T.gap(1, y, y), gz = T.gap(2, z, z);
+    const double s2 = gy * gy + gz * gz;
+    if (s2 * T.h2 > top.lim_d) return P;
+    uint32_t S[3], E[3];
+    if (r == 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { S[j] = cS[j]; E[j] = cE[j]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { S[j] = __shfl(mS[j], r - 1, GL); E[j] = __shfl(mE[j], r - 1, GL); }
+    }
+    uint32_t n[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int x = c0 - 1 + j;
+      const double g = T.gap(0, x, x);
+      n[j] = ((g * g + s2) * T.h2 > top.lim_d) ? 0u : (E[j] - S[j]);   // cells outside the grid have S == E == 0
+    }
+    P.a0 = S[0]; P.a1 = S[1]; P.a2 = S[2];
+    P.n0 = n[0]; P.n01 = n[0] + n[1]; P.T = P.n01 + n[2];
+    return P;
+  };
+  auto request = [&](const RowPlan& P, Rec (&R)[NB]) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const uint32_t v = b * GL + L;
+      if (v < P.T) R[b] = src[P.addr(v)];
+    }
+  };
+  auto rank_batch = [&](const RowPlan& P, const Rec (&R)[NB]) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if ((uint32_t)(b * GL) < P.T) {            // group-uniform
+        const uint32_t v = b * GL + L;
+        double d = INFINITY;
+        uint32_t id = PT_NOIDX_U;
+        if (v < P.T) { d = dist2(T.q, R[b]); id = R[b].id; }
+        top.offer(d, id, gshift);
+      }
+    }
+    for (uint32_t vb = NB * GL; vb < P.T; vb += GL) {   // rows longer than one batch (dense cells)
+      const uint32_t v = vb + L;
+      double d = INFINITY;
+      uint32_t id = PT_NOIDX_U;
+      if (v < P.T) { const Rec r = src[P.addr(v)]; d = dist2(T.q, r); id = r.id; }
+      top.offer(d, id, gshift);
+    }
+  };
+
+  // ---- ring 1, phase B: rows in centre-first order, the next row's records in flight while this one is ranked
+  {
+    Rec Rn[NB];
+    RowPlan Pn = make_plan(0);
+    request(Pn, Rn);
+#pragma unroll 1
+    for (int r = 0; r < 9; ++r) {
+      Rec Rc[NB];
+      const RowPlan Pc = Pn;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) Rc[b] = Rn[b];
+      if (r + 1 < 9) {
+        Pn = make_plan(r + 1);        // planned under the limit as it is now: conservative, never wrong
+        request(Pn, Rn);
+      }
+      rank_batch(Pc, Rc);
+    }
+  }
+
+  // ---- rings >= 2: only while something outside the scanned box can still beat the limit ---------------------------
+  for (int r = 1;; ++r) {
     // every unscanned point lies beyond one of the box faces that still has cells behind it
     bool covered = true;
     double dout = INFINITY;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const int lo = S.c[a] - r, hi = S.c[a] + r;
-      if (lo > 0) { covered = false; dout = fmin(dout, S.u[a] - (double)lo); }
-      if (hi < gp.dim[a] - 1) { covered = false; dout = fmin(dout, (double)(hi + 1) - S.u[a]); }
+      const int lo = T.c[a] - r, hi = T.c[a] + r;
+      if (lo > 0) { covered = false; dout = fmin(dout, T.u[a] - (double)lo); }
+      if (hi < gp.dim[a] - 1) { covered = false; dout = fmin(dout, (double)(hi + 1) - T.u[a]); }
     }
     if (covered) break;
     dout = fmax(dout - PT_CELL_EPS, 0.0);
-    if (dout * dout * S.h2 > S.lim_d) break;
+    if (dout * dout * T.h2 > top.lim_d) break;
+    const int rr = r + 1;                      // scan the shell box(rr) \ box(rr-1)
+    const int x0 = max(c0 - rr, 0), x1 = min(c0 + rr, gp.dim[0] - 1);
+    const int y0 = max(c1 - rr, 0), y1 = min(c1 + rr, gp.dim[1] - 1);
+    const int z0 = max(c2 - rr, 0), z1 = min(c2 + rr, gp.dim[2] - 1);
+    for (int z = z0; z <= z1; ++z)
+      for (int y = y0; y <= y1; ++y) {
+        const bool shell = (z == c2 - rr) || (z == c2 + rr) || (y == c1 - rr) || (y == c1 + rr);
+        if (shell) scan_row_generic<Rec, KPL>(gp, src, cs, T, top, gshift, x0, x1, y, z);
+        else {
+          if (c0 - rr >= 0) scan_row_generic<Rec, KPL>(gp, src, cs, T, top, gshift, c0 - rr, c0 - rr, y, z);
+          if (c0 + rr <= gp.dim[0] - 1) scan_row_generic<Rec, KPL>(gp, src, cs, T, top, gshift, c0 + rr, c0 + rr, y, z);
+        }
+      }
   }
 
-  const size_t row = (size_t)T.id * (size_t)k;
+  const size_t row = (size_t)tr.id * (size_t)k;
 #pragma unroll
   for (int j = 0; j < KPL; ++j) {
-    const int e = S.L * KPL + j;
+    const int e = L * KPL + j;
     if (e < k) {
-      out_idx[row + e] = S.li[j];
-      if (out_d2) out_d2[row + e] = S.ld[j];
+      out_idx[row + e] = top.li[j];
+      if (out_d2) out_d2[row + e] = top.ld[j];
     }
   }
 }
