@@ -80,20 +80,27 @@ struct TopList {
     lim_d = bound;
     lim_i = PT_NOIDX_U;
   }
-  __device__ bool accepts(double d, uint32_t i) const { return key_lt(d, i, lim_d, lim_i); }
+  // cheap pre-test against the cached limit (may be stale, i.e. too permissive -- never too strict)
+  __device__ bool may_accept(double d, uint32_t i) const { return key_lt(d, i, lim_d, lim_i); }
 
-  // insert (xd, xi), known by every lane of the group, into the sorted list; the last entry falls off
-  __device__ void insert(double xd, uint32_t xi) {
+  // Try to insert (xd, xi), known by every lane of the group.  The exact acceptance test is the comparison with the
+  // entry of rank k-1, which lives in lane hl: its verdict reaches the group through one ballot bit, so the k-th
+  // entry itself never has to be broadcast.  Returns whether the list changed.
+  __device__ bool try_insert(double xd, uint32_t xi, int gshift) {
     bool cj[KPL];
 #pragma unroll
     for (int j = 0; j < KPL; ++j) cj[j] = key_lt(xd, xi, ld[j], li[j]);
-    // the lane below hands over its last entry if the new key sorts before it
-    const double pd = dpp_f64<DPP_SHR1>(ld[KPL - 1]);
-    const uint32_t pi = dpp_u32<DPP_SHR1>(li[KPL - 1]);
+    bool csel = cj[0];
+#pragma unroll
+    for (int j = 1; j < KPL; ++j) if (hr == j) csel = cj[j];
+    const bool acc = ((__ballot(csel) >> (gshift + hl)) & 1ull) != 0ull;   // group-uniform
+    if (!acc) return false;
+    // one-position shift: the lane below hands over its last entry if the new key sorts before it.
     // (every cross-lane move is executed by ALL lanes of the group: never under a lane-dependent branch, or the
     //  source lane may be masked off; lane 0's incoming value is discarded arithmetically instead)
-    const uint32_t pcv = dpp_u32<DPP_SHR1>(cj[KPL - 1] ? 1u : 0u) & notfirst;
-    const bool pc = pcv != 0u;
+    const double pd = dpp_f64<DPP_SHR1>(ld[KPL - 1]);
+    const uint32_t pi = dpp_u32<DPP_SHR1>(li[KPL - 1]);
+    const bool pc = (dpp_u32<DPP_SHR1>(cj[KPL - 1] ? 1u : 0u) & notfirst) != 0u;
 #pragma unroll
     for (int j = KPL - 1; j >= 1; --j) {
       if (cj[j - 1]) { ld[j] = ld[j - 1]; li[j] = li[j - 1]; }
@@ -101,7 +108,11 @@ struct TopList {
     }
     if (pc) { ld[0] = pd; li[0] = pi; }
     else if (cj[0]) { ld[0] = xd; li[0] = xi; }
-    // new acceptance limit: the entry of rank k-1, unless the caller's bound is tighter
+    return true;
+  }
+
+  // re-read the limit after insertions: the entry of rank k-1, unless the caller's bound is tighter
+  __device__ void refresh_limit() {
     double kd;
     uint32_t ki;
     if (fullk) {
@@ -121,14 +132,18 @@ struct TopList {
 
   // offer one candidate per lane (d = +inf / id = NOIDX for lanes without one)
   __device__ void offer(double d, uint32_t id, int gshift) {
-    const bool pass = accepts(d, id);
+    const bool pass = may_accept(d, id) && !(d > bnd_d);
     uint32_t mask = (uint32_t)(__ballot(pass) >> gshift) & 0xFFu;
-    while (mask) {
-      const int t = __ffs(mask) - 1;
-      mask &= mask - 1;
-      const double xd = __shfl(d, t, GL);
-      const uint32_t xi = __shfl(id, t, GL);
-      if (accepts(xd, xi)) insert(xd, xi);   // re-test: the limit may have tightened within this step
+    if (mask) {
+      bool changed = false;
+      do {
+        const int t = __ffs(mask) - 1;
+        mask &= mask - 1;
+        const double xd = __shfl(d, t, GL);
+        const uint32_t xi = __shfl(id, t, GL);
+        changed |= try_insert(xd, xi, gshift);
+      } while (mask);
+      if (changed) refresh_limit();
     }
   }
 };
