@@ -37,6 +37,7 @@ struct pt_ctx {
   std::string err;
   double rho = 8.0;
   int sync = 1;
+  int tile = 1;                // 1: tile kernel + group kernel for leftovers (fp32, unbounded); 0: group kernel only
   size_t dev_bytes = 0;
 
   // source cloud (slab-local when built from a slab)
@@ -57,7 +58,7 @@ struct pt_ctx {
   DevBuf ttb_mem;
 
   // scratch
-  DevBuf bbox6, counter, q_idx, q_d2, b_rgb, b_nrm, aos_stage, misc, bounds;
+  DevBuf bbox6, counter, q_idx, q_d2, b_rgb, b_nrm, aos_stage, misc, bounds, todo;
   uint64_t* h_bbox = nullptr;   // pinned
   uint32_t* h_counter = nullptr;
 
@@ -246,18 +247,31 @@ int query_resident(pt_ctx* c, int k, const double* bound2_dev, uint32_t* idx_dev
   const uint32_t m = (uint32_t)c->m;
   RES(c, c->trec, std::max<size_t>(m, 1) * recsize(c->tgt_type));
   RES(c, c->trec_tmp, std::max<size_t>(m, 1) * recsize(c->tgt_type));
+  RES(c, c->todo, std::max<size_t>(m, 1) * sizeof(uint32_t));
   { int r = make_tables(c, c->ttb_mem, c->ttb, (uint32_t)c->gp.nblocks, m, recsize(c->tgt_type)); if (r != PT_OK) return r; }
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (c->tgt_type == PT_F32) {
     const float* x = (const float*)c->t_xyz.p;
     pt_launch_grid_sort<float, RecF>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecF*)c->trec.p, (RecF*)c->trec_tmp.p, nullptr, c->ttb, c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecF*)c->trec.p, m, k, bound2_dev, idx_dev, d2_dev, c->stream);
+    if (c->tile && !bound2_dev && m) {
+      uint32_t* todo_n = (uint32_t*)c->counter.p + 4;
+      HIPCHK(c, hipMemsetAsync(todo_n, 0, 4, c->stream));
+      pt_launch_knn_tile(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecF*)c->trec.p, c->ttb.block_start, k, idx_dev, d2_dev,
+                         (uint32_t*)c->todo.p, todo_n, c->stream);
+      pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecF*)c->trec.p, m, k, nullptr, idx_dev, d2_dev,
+                          (const uint32_t*)c->todo.p, todo_n, c->stream);
+      HIPCHK(c, hipMemcpyAsync(c->h_counter + 4, todo_n, 4, hipMemcpyDeviceToHost, c->stream));
+    } else {
+      pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecF*)c->trec.p, m, k, bound2_dev, idx_dev, d2_dev,
+                          nullptr, nullptr, c->stream);
+    }
   } else {
     const double* x = (const double*)c->t_xyz.p;
     pt_launch_grid_sort<double, RecD>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecD*)c->trec.p, (RecD*)c->trec_tmp.p, nullptr, c->ttb, c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecD*)c->trec.p, m, k, bound2_dev, idx_dev, d2_dev, c->stream);
+    pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecD*)c->trec.p, m, k, bound2_dev, idx_dev, d2_dev,
+                        nullptr, nullptr, c->stream);
   }
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, hipGetLastError());
@@ -274,6 +288,7 @@ int query_resident(pt_ctx* c, int k, const double* bound2_dev, uint32_t* idx_dev
     c->st.ms_query = b;
     c->st.ms_kernel[6] = a;
     c->st.ms_kernel[7] = b;
+    c->st.n_leftover = (c->tile && !bound2_dev && m && c->tgt_type == PT_F32) ? c->h_counter[4] : 0;
   }
   return PT_OK;
 }
@@ -326,7 +341,7 @@ void pt_ctx_destroy(pt_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in_xyz, &c->in_gidx, &c->attr, &c->rec, &c->rec_tmp, &c->cell_start, &c->stb_mem, &c->t_xyz, &c->t_gidx, &c->trec,
-                   &c->trec_tmp, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds};
+                   &c->trec_tmp, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo};
   for (DevBuf* b : all) release(c, *b);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);
@@ -346,6 +361,7 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!c || !name) return PT_ERR_ARG;
   if (!strcmp(name, "rho")) { if (!(value >= 0.25 && value <= 4096)) return fail(c, PT_ERR_ARG, "rho out of range"); c->rho = value; return PT_OK; }
   if (!strcmp(name, "sync")) { c->sync = value != 0; return PT_OK; }
+  if (!strcmp(name, "tile")) { c->tile = value != 0; return PT_OK; }
   return fail(c, PT_ERR_ARG, "unknown parameter '%s'", name);
 }
 

@@ -63,4 +63,33 @@ __device__ inline void pt_cell_of(const GridParams& gp, const Rec& r, int& cx, i
   cy = pt_cell_axis((double)r.y, gp.bbmin[1], gp.inv_h, gp.dim[1]);
   cz = pt_cell_axis((double)r.z, gp.bbmin[2], gp.inv_h, gp.dim[2]);
 }
+
+// ---- workgroup scan helpers (256-thread workgroups) ---------------------------------------------------
+__device__ inline uint32_t wave_incl_scan(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+// exclusive scan of one value per thread over a 256-thread workgroup; wsum: LDS scratch of 4 words
+__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* wsum, uint32_t& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t incl = wave_incl_scan(v);
+  __syncthreads();
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  uint32_t off = 0;
+  total = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t ws = wsum[i];
+    if (i < w) off += ws;
+    total += ws;
+  }
+  return off + incl - v;
+}
+
 #endif

@@ -82,33 +82,6 @@ __device__ inline bool tile_range(const uint32_t* __restrict__ seg_start, const 
   return true;
 }
 
-__device__ inline uint32_t wave_incl_scan(uint32_t v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(v, o);
-    if (lane >= o) v += t;
-  }
-  return v;
-}
-// exclusive scan of one value per thread over a 256-thread workgroup; wsum: LDS scratch of 4 words
-__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* wsum, uint32_t& total) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t incl = wave_incl_scan(v);
-  __syncthreads();
-  if (lane == 63) wsum[w] = incl;
-  __syncthreads();
-  uint32_t off = 0;
-  total = 0;
-#pragma unroll
-  for (int i = 0; i < WG / 64; ++i) {
-    const uint32_t ws = wsum[i];
-    if (i < w) off += ws;
-    total += ws;
-  }
-  return off + incl - v;
-}
-
 // ---- bounding box ------------------------------------------------------------------------------
 __device__ inline uint64_t enc_f64(double d) {
   const uint64_t b = (uint64_t)__double_as_longlong(d);

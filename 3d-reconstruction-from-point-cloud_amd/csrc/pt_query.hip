@@ -206,13 +206,14 @@ struct RowPlan {
 template <class Rec, int KPL>
 __global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __restrict__ src, const uint32_t* __restrict__ cs,
                                                  const Rec* __restrict__ tgt, uint32_t m, int k, const double* __restrict__ bound2,
-                                                 uint32_t* __restrict__ out_idx, double* __restrict__ out_d2) {
+                                                 uint32_t* __restrict__ out_idx, double* __restrict__ out_d2,
+                                                 const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_n) {
   constexpr int NB = Batch<Rec>::N;
   const uint32_t gid = (blockIdx.x * WG + threadIdx.x) / GL;
-  if (gid >= m) return;                       // whole groups leave together
+  if (gid >= (list ? *list_n : m)) return;    // whole groups leave together
   const int L = threadIdx.x & (GL - 1);
   const int gshift = (threadIdx.x & 63) & ~(GL - 1);
-  const Rec tr = tgt[gid];
+  const Rec tr = tgt[list ? list[gid] : gid];  // `list`: positions (in the sorted target array) left over by the tile kernel
   TargetGeom T;
   T.q[0] = (double)tr.x; T.q[1] = (double)tr.y; T.q[2] = (double)tr.z;
   T.h2 = gp.h * gp.h;
@@ -362,6 +363,298 @@ __global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __res
   }
 }
 
+
+// =====================================================================================================================
+// Tile kernel: one 8x8x8-cell block per workgroup, ONE THREAD PER TARGET, candidates staged in LDS.
+//
+// Why a second kernel: the 8-lanes-per-target kernel above is VALU-issue-bound (every cross-lane insertion runs with
+// 1/8 of the wave doing useful work).  Targets of one block share their 3x3x3 neighbourhoods, so the 10x10x10-cell
+// region around the block is staged ONCE into LDS (coalesced row copies) and every lane then ranks its own target:
+//   pass 1  fp32 distances, running k smallest VALUES only (v_med3 chain, no payload)  ->  a proven upper bound on the
+//           exact k-th squared distance (see `kth_bound32`);
+//   pass 2  re-scan, queue the positions of the few candidates within that bound (per-lane queue in LDS);
+//   pass 3  exact fp64 metric + total order (d2, index) on the queued candidates only.
+// Targets that ring 1 cannot settle (k-th neighbour farther than the region guarantees, queue overflow, region larger
+// than the LDS budget) are appended to `todo` and finished by the group kernel.  fp32 records only (the fp32
+// pre-filter needs exact fp32 inputs).
+constexpr int TILE_R = 10, TILE_CELLS = TILE_R * TILE_R * TILE_R;
+constexpr int TILE_CAP = 8448;       // records staged per tile (132 KB); a uniform rho = 8 region holds 8000 +- 90
+constexpr int TILE_Q = 32;           // queue entries per lane
+
+__device__ inline float dist2_f32(float qx, float qy, float qz, const RecF& r) {
+  const float dx = qx - r.x, dy = qy - r.y, dz = qz - r.z;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+// d32 is computed from exact fp32 inputs with 3 sub, 3 mul, 2 add: relative error < 2^-21 (all terms >= 0).
+// If b = k-th smallest d32 of a candidate set, then k candidates have exact d2 <= b*(1+2^-21), so the exact k-th d2
+// D_k <= b*(1+2^-21), and every candidate with exact d2 <= D_k has d32 <= b*(1+2^-21)^2 < b*(1+2^-18).
+__device__ inline float kth_bound32(float b) { return b * 1.0000038146972656f + 1e-30f; }   // 1 + 2^-18, + denormal slack
+
+template <int K>
+__global__ __launch_bounds__(WG, 1) void knn_tile_kernel(GridParams gp, const RecF* __restrict__ src, const uint32_t* __restrict__ cs,
+                                                      const RecF* __restrict__ tgt, const uint32_t* __restrict__ tblock_start, int k,
+                                                      uint32_t* __restrict__ out_idx, double* __restrict__ out_d2,
+                                                      uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_n) {
+  __shared__ __attribute__((aligned(16))) RecF lrec[TILE_CAP];
+  __shared__ uint32_t lstart[TILE_CELLS + 8];
+  __shared__ __attribute__((aligned(16))) uint16_t queue[WG * TILE_Q];     // first 4000 bytes double as gstart[] during staging
+  __shared__ uint32_t wsum[4];
+  uint32_t* gstart = reinterpret_cast<uint32_t*>(queue);
+  static_assert(sizeof(queue) >= TILE_CELLS * sizeof(uint32_t), "gstart aliases the queue");
+
+  const uint32_t b = blockIdx.x;
+  const uint32_t ts = tblock_start[b], te = tblock_start[b + 1];
+  if (ts == te) return;
+  // block id -> cell origin of the block
+  const uint32_t macro = b >> 9, m9 = b & 511u;
+  const int bx = (int)(macro % (uint32_t)gp.mdim[0]) * 8 + (int)((m9 & 1u) | ((m9 >> 2) & 2u) | ((m9 >> 4) & 4u));
+  const int by = (int)((macro / (uint32_t)gp.mdim[0]) % (uint32_t)gp.mdim[1]) * 8 + (int)(((m9 >> 1) & 1u) | ((m9 >> 3) & 2u) | ((m9 >> 5) & 4u));
+  const int bz = (int)(macro / (uint32_t)(gp.mdim[0] * gp.mdim[1])) * 8 + (int)(((m9 >> 2) & 1u) | ((m9 >> 4) & 2u) | ((m9 >> 6) & 4u));
+  const int ox = bx * 8 - 1, oy = by * 8 - 1, oz = bz * 8 - 1;          // cell coordinates of region cell (0,0,0)
+
+  // ---- A: region cell table (global start + count of each of the 1000 cells), LDS offsets by a workgroup scan
+  {
+    uint32_t cnt[4], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = threadIdx.x * 4 + i;
+      cnt[i] = 0;
+      if (c < TILE_CELLS) {
+        const int x = ox + c % TILE_R, y = oy + (c / TILE_R) % TILE_R, z = oz + c / (TILE_R * TILE_R);
+        uint32_t gs = 0;
+        if (x >= 0 && x < gp.dim[0] && y >= 0 && y < gp.dim[1] && z >= 0 && z < gp.dim[2]) {
+          const uint32_t key = cell_key(gp, x, y, z);
+          gs = cs[key];
+          cnt[i] = cs[key + 1] - gs;
+        }
+        gstart[c] = gs;
+      }
+      sum += cnt[i];
+    }
+    uint32_t tot;
+    uint32_t ex = block_excl_scan(sum, wsum, tot);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = threadIdx.x * 4 + i;
+      if (c < TILE_CELLS) lstart[c] = ex;
+      ex += cnt[i];
+    }
+    if (threadIdx.x == 0) lstart[TILE_CELLS] = tot;
+  }
+  __syncthreads();
+  const uint32_t P = lstart[TILE_CELLS];
+  if (P > (uint32_t)TILE_CAP) {                     // denser than the LDS budget: the group kernel takes the whole tile
+    for (uint32_t t = ts + threadIdx.x; t < te; t += WG) todo[atomicAdd(todo_n, 1u)] = t;
+    return;
+  }
+  // ---- B: stage the region.  Cells x = 1..8 of a region row are one contiguous run in HBM and in LDS: a wave copies
+  //         a row with two instructions (<= 128 records); the 200 halo cells (x = 0 and 9) are copied by 8-lane groups.
+  //         With one workgroup per CU nothing else hides HBM latency, so every load of a batch is issued before the
+  //         first LDS store: 2 + 1 exposed latencies per tile instead of one per row.
+  {
+    const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(src);     // records move as raw 16-byte words
+    uint4* l4 = reinterpret_cast<uint4*>(lrec);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int ROWS_PER_WAVE = TILE_R * TILE_R / (WG / 64);      // 25
+    constexpr int RB = 13;                                          // rows per batch
+    bool long_rows = false;
+#pragma unroll
+    for (int b0 = 0; b0 < ROWS_PER_WAVE; b0 += RB) {
+      uint4 t0[RB], t1[RB];
+      uint32_t la[RB], len[RB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int ri = (b0 + i < ROWS_PER_WAVE) ? b0 + i : ROWS_PER_WAVE - 1;
+        const int c1 = (w + ri * (WG / 64)) * TILE_R + 1;
+        la[i] = lstart[c1];
+        len[i] = (b0 + i < ROWS_PER_WAVE) ? lstart[c1 + 8] - la[i] : 0u;
+        const uint32_t ga = gstart[c1];
+        t0[i] = make_uint4(0, 0, 0, 0); t1[i] = make_uint4(0, 0, 0, 0);
+        if ((uint32_t)lane < len[i]) t0[i] = src4[ga + lane];
+        if ((uint32_t)lane + 64u < len[i]) t1[i] = src4[ga + lane + 64u];
+        long_rows |= len[i] > 128u;
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        if ((uint32_t)lane < len[i]) l4[la[i] + lane] = t0[i];
+        if ((uint32_t)lane + 64u < len[i]) l4[la[i] + lane + 64u] = t1[i];
+      }
+    }
+    if (long_rows) {                                                // very dense rows: the rest synchronously
+      for (int ri = 0; ri < ROWS_PER_WAVE; ++ri) {
+        const int c1 = (w + ri * (WG / 64)) * TILE_R + 1;
+        const uint32_t la = lstart[c1], len = lstart[c1 + 8] - la, ga = gstart[c1];
+        for (uint32_t p = lane + 128u; p < len; p += 64) l4[la + p] = src4[ga + p];
+      }
+    }
+    const int g8 = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    constexpr int NHALO = 2 * TILE_R * TILE_R;
+    constexpr int HC = (NHALO + WG / 8 - 1) / (WG / 8);             // 7 halo cells per 8-lane group
+    uint4 h0[HC], h1[HC];
+    uint32_t hla[HC], hlen[HC];
+    bool long_cells = false;
+#pragma unroll
+    for (int i = 0; i < HC; ++i) {
+      const int hcr = g8 + i * (WG / 8);
+      const int hc = hcr < NHALO ? hcr : NHALO - 1;
+      const int c = (hc >> 1) * TILE_R + ((hc & 1) ? TILE_R - 1 : 0);
+      hla[i] = lstart[c];
+      hlen[i] = hcr < NHALO ? lstart[c + 1] - hla[i] : 0u;
+      const uint32_t ga = gstart[c];
+      h0[i] = make_uint4(0, 0, 0, 0); h1[i] = make_uint4(0, 0, 0, 0);
+      if ((uint32_t)l8 < hlen[i]) h0[i] = src4[ga + l8];
+      if ((uint32_t)l8 + 8u < hlen[i]) h1[i] = src4[ga + l8 + 8u];
+      long_cells |= hlen[i] > 16u;
+    }
+#pragma unroll
+    for (int i = 0; i < HC; ++i) {
+      if ((uint32_t)l8 < hlen[i]) l4[hla[i] + l8] = h0[i];
+      if ((uint32_t)l8 + 8u < hlen[i]) l4[hla[i] + l8 + 8u] = h1[i];
+    }
+    if (long_cells) {
+      for (int hc = g8; hc < NHALO; hc += WG / 8) {
+        const int c = (hc >> 1) * TILE_R + ((hc & 1) ? TILE_R - 1 : 0);
+        const uint32_t la = lstart[c], len = lstart[c + 1] - la, ga = gstart[c];
+        for (uint32_t p = l8 + 16u; p < len; p += 8) l4[la + p] = src4[ga + p];
+      }
+    }
+  }
+  __syncthreads();                                  // gstart is dead from here on: the queue takes its place
+
+  // ---- C: one thread per target -------------------------------------------------------------------------------------
+  const double h2 = gp.h * gp.h;
+  for (uint32_t t = ts + threadIdx.x; t < te; t += WG) {
+    const RecF tr = tgt[t];
+    const double q[3] = {(double)tr.x, (double)tr.y, (double)tr.z};
+    double u[3];
+    int cc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      u[a] = (q[a] - gp.bbmin[a]) * gp.inv_h;
+      cc[a] = (int)fmin(fmax(u[a], 0.0), (double)(gp.dim[a] - 1));
+    }
+    const int rx = cc[0] - ox, ry = cc[1] - oy, rz = cc[2] - oz;       // region coordinates of the target's cell, in [1, 8]
+    // squared lower bound (cell units) from the target to cell interval [lo, hi] along axis a
+    auto gap = [&](int a, int lo, int hi) -> double {
+      const double g = fmax((double)lo - u[a], u[a] - (double)(hi + 1)) - PT_CELL_EPS;
+      return fmax(g, 0.0);
+    };
+    // LDS range of the cells of row r that may hold a point with d2 <= lim (lim in world units, +inf = everything)
+    auto row_range = [&](int r, double lim, uint32_t& pa, uint32_t& pe) {
+      pa = pe = 0;
+      const int y = cc[1] + row_dy(r), z = cc[2] + row_dz(r);
+      const double gy = gap(1, y, y), gz = gap(2, z, z);
+      const double s2 = gy * gy + gz * gz;
+      if (s2 * h2 > lim) return;
+      const int c0 = ((rz + row_dz(r)) * TILE_R + (ry + row_dy(r))) * TILE_R + (rx - 1);
+      int ja = 0, jb = 2;
+      { const double g = gap(0, cc[0] - 1, cc[0] - 1); if ((g * g + s2) * h2 > lim) ja = 1; }
+      { const double g = gap(0, cc[0] + 1, cc[0] + 1); if ((g * g + s2) * h2 > lim) jb = 1; }
+      pa = lstart[c0 + ja];
+      pe = lstart[c0 + jb + 1];
+    };
+
+    // pass 1: k smallest fp32 distances (values only)
+    float l32[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) l32[j] = INFINITY;
+#pragma unroll 1
+    for (int r = 0; r < 9; ++r) {
+      uint32_t pa, pe;
+      float kv = l32[0];
+#pragma unroll
+      for (int j = 1; j < K; ++j) kv = (j == k - 1) ? l32[j] : kv;
+      row_range(r, (double)kth_bound32(kv), pa, pe);
+      for (uint32_t p = pa; p < pe; p += 4) {        // 4 LDS reads in flight per lane (one wave per SIMD: ILP is all there is)
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t pi = min(p + i, pe - 1);
+          x[i] = dist2_f32(tr.x, tr.y, tr.z, lrec[pi]);
+          if (p + i >= pe) x[i] = INFINITY;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float prev = l32[0];
+          l32[0] = fminf(x[i], prev);
+#pragma unroll
+          for (int j = 1; j < K; ++j) { const float cur = l32[j]; l32[j] = __builtin_amdgcn_fmed3f(x[i], prev, cur); prev = cur; }
+        }
+      }
+    }
+    // pass 2: queue the candidates within the proven bound
+    float kv2 = l32[0];
+#pragma unroll
+    for (int j = 1; j < K; ++j) kv2 = (j == k - 1) ? l32[j] : kv2;
+    const float thr = kth_bound32(kv2);
+    uint32_t nq = 0;
+    bool overflow = false;
+#pragma unroll 1
+    for (int r = 0; r < 9; ++r) {
+      uint32_t pa, pe;
+      row_range(r, (double)thr, pa, pe);
+      for (uint32_t p = pa; p < pe; p += 4) {
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t pi = min(p + i, pe - 1);
+          x[i] = dist2_f32(tr.x, tr.y, tr.z, lrec[pi]);
+          if (p + i >= pe) x[i] = INFINITY;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (p + i < pe && x[i] <= thr) {            // (thr may be +inf: the padding lanes must not pass)
+            if (nq < (uint32_t)TILE_Q) queue[nq * WG + threadIdx.x] = (uint16_t)(p + i); else overflow = true;
+            ++nq;
+          }
+        }
+      }
+    }
+    // pass 3: exact metric and total order on the queued candidates
+    double ld[K];
+    uint32_t li[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { ld[j] = INFINITY; li[j] = PT_NOIDX_U; }
+    const uint32_t nqc = min(nq, (uint32_t)TILE_Q);
+    for (uint32_t e = 0; e < nqc; ++e) {
+      const RecF r = lrec[queue[e * WG + threadIdx.x]];
+      const double d = dist2(q, r);
+      bool c[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) c[j] = key_lt(d, r.id, ld[j], li[j]);
+#pragma unroll
+      for (int j = K - 1; j >= 1; --j) {
+        ld[j] = c[j - 1] ? ld[j - 1] : (c[j] ? d : ld[j]);
+        li[j] = c[j - 1] ? li[j - 1] : (c[j] ? r.id : li[j]);
+      }
+      ld[0] = c[0] ? d : ld[0];
+      li[0] = c[0] ? r.id : li[0];
+    }
+    // is ring 1 enough?  (same face test as the group kernel)
+    double kd = ld[0];
+#pragma unroll
+    for (int j = 1; j < K; ++j) if (j == k - 1) kd = ld[j];
+    bool covered = true;
+    double dout = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int lo = cc[a] - 1, hi = cc[a] + 1;
+      if (lo > 0) { covered = false; dout = fmin(dout, u[a] - (double)lo); }
+      if (hi < gp.dim[a] - 1) { covered = false; dout = fmin(dout, (double)(hi + 1) - u[a]); }
+    }
+    dout = fmax(dout - PT_CELL_EPS, 0.0);
+    const bool done = !overflow && (covered || dout * dout * h2 > kd);
+    if (done) {
+      const size_t row = (size_t)tr.id * (size_t)k;
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        if (j < k) { out_idx[row + j] = li[j]; if (out_d2) out_d2[row + j] = ld[j]; }
+    } else {
+      todo[atomicAdd(todo_n, 1u)] = t;
+    }
+  }
+}
+
 // ---- G-way merge of candidate lists under (d2, idx): one thread per (target, list slot) --------------
 __global__ __launch_bounds__(WG) void merge_kernel(const uint32_t* __restrict__ idx_lists, const double* __restrict__ d2_lists, int g,
                                                    uint32_t m, int k, uint32_t* __restrict__ idx_out, double* __restrict__ d2_out) {
@@ -412,20 +705,32 @@ __global__ __launch_bounds__(WG) void slab_need_kernel(const T* __restrict__ x, 
 
 template <class Rec>
 void pt_launch_knn(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const Rec* tgt, uint32_t m, int k, const double* bound2,
-                   uint32_t* out_idx, double* out_d2, hipStream_t s) {
+                   uint32_t* out_idx, double* out_d2, const uint32_t* list, const uint32_t* list_n, hipStream_t s) {
   if (!m) return;
   const uint32_t nwg = (uint32_t)(((uint64_t)m * GL + WG - 1) / WG);
   if (k <= 8)
-    hipLaunchKernelGGL((knn_kernel<Rec, 1>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2);
+    hipLaunchKernelGGL((knn_kernel<Rec, 1>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n);
   else if (k <= 16)
-    hipLaunchKernelGGL((knn_kernel<Rec, 2>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2);
+    hipLaunchKernelGGL((knn_kernel<Rec, 2>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n);
   else
-    hipLaunchKernelGGL((knn_kernel<Rec, 4>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2);
+    hipLaunchKernelGGL((knn_kernel<Rec, 4>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n);
 }
 template void pt_launch_knn<RecF>(const GridParams&, const RecF*, const uint32_t*, const RecF*, uint32_t, int, const double*, uint32_t*, double*,
-                                  hipStream_t);
+                                  const uint32_t*, const uint32_t*, hipStream_t);
 template void pt_launch_knn<RecD>(const GridParams&, const RecD*, const uint32_t*, const RecD*, uint32_t, int, const double*, uint32_t*, double*,
-                                  hipStream_t);
+                                  const uint32_t*, const uint32_t*, hipStream_t);
+
+// tile kernel over all blocks; targets it cannot settle are appended to todo[*todo_n] (todo_n zeroed by the caller)
+void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* cell_start, const RecF* tgt, const uint32_t* tblock_start, int k,
+                        uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, hipStream_t s) {
+  const uint32_t nb = (uint32_t)gp.nblocks;
+  if (k <= 8)
+    hipLaunchKernelGGL(knn_tile_kernel<8>, dim3(nb), dim3(WG), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n);
+  else if (k <= 16)
+    hipLaunchKernelGGL(knn_tile_kernel<16>, dim3(nb), dim3(WG), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n);
+  else
+    hipLaunchKernelGGL(knn_tile_kernel<32>, dim3(nb), dim3(WG), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n);
+}
 
 void pt_launch_merge(const uint32_t* idx_lists, const double* d2_lists, int g, uint32_t m, int k, uint32_t* idx_out, double* d2_out,
                      hipStream_t s) {

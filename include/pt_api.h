@@ -82,6 +82,7 @@ typedef struct pt_stats_t {
    * [0] bbox reduce + readback, [1] pass-1 histogram, [2] pass-1 scatter, [3] pass-2 histogram + block scan,
    * [4] pass-2 scatter, [5] finalize (cell sort), [6] target sort (all passes), [7] k-NN kernel */
   double ms_kernel[8];
+  uint64_t n_leftover;      /* targets of the last query that the tile kernel handed to the group kernel */
 } pt_stats_t;
 
 /* ---- context ------------------------------------------------------------------------ */
@@ -92,7 +93,8 @@ void pt_ctx_destroy(pt_ctx*);
  * stream).  NULL = the context's own stream. */
 int  pt_set_stream(pt_ctx*, void* hip_stream);
 /* Tunables: "rho" (target points per grid cell, default 8), "sync" (1 = every call blocks until
- * the GPU is done, default 1; 0 = _dev calls only enqueue). */
+ * the GPU is done, default 1; 0 = _dev calls only enqueue), "tile" (1 = tile kernel + group kernel for its
+ * leftovers, default; 0 = group kernel only). */
 int  pt_set_param(pt_ctx*, const char* name, double value);
 const char* pt_last_error(pt_ctx*);
 int  pt_stats(pt_ctx*, pt_stats_t* out);

@@ -54,6 +54,25 @@ def test_cell_size_does_not_change_results(pkg, oracle, rho):
         _check_exact(p.query(tgt, 8), oracle.knn_bruteforce(src, tgt, 8), "rho=%g" % rho)
 
 
+@pytest.mark.parametrize("k", [1, 8, 13, 16, 20, 32])
+def test_tile_kernel_and_group_kernel_agree(pkg, oracle, k):
+    """The two k-NN kernels (one thread per target over an LDS-staged tile / 8 lanes per target) must give the same
+    bits as each other and as the oracle; the tile kernel may only hand a small share of the targets over."""
+    src, tgt = oracle.synth_xyz(21, 0, 400000), oracle.synth_xyz(21, 1, 30000)
+    want = oracle.KdTree(src).query(tgt, k)
+    with pkg.PointsTransfer(device=0) as p:
+        p.build(src)
+        p.set_param("tile", 1)
+        got_tile = p.query(tgt, k)
+        left = p.stats()["n_leftover"]
+        p.set_param("tile", 0)
+        got_group = p.query(tgt, k)
+        assert p.stats()["n_leftover"] == 0
+    _check_exact(got_tile, want, "tile k=%d" % k)
+    _check_exact(got_group, want, "group k=%d" % k)
+    assert left < 0.5 * tgt.shape[1], "tile kernel handed over %d of %d targets" % (left, tgt.shape[1])
+
+
 def test_device_generator_matches_oracle(pkg, oracle):
     import torch
     n, m, k, seed = 100000, 10000, 8, 0xC2

@@ -15,4 +15,4 @@ with pkg.PointsTransfer(device=0) as p:
     for it in range(steps):
         p.rebuild(); p.query_resident_dev(k, idx, d2); p.blend_dev(idx, d2, m, k, 0, rgb, nrm)
     torch.cuda.synchronize()
-    print(name, p.stats()["ms_kernel"])
+    st = p.stats(); print(name, st["ms_kernel"], "leftover", st["n_leftover"])
