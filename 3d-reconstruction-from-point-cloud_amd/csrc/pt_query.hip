@@ -365,21 +365,27 @@ __global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __res
 
 
 // =====================================================================================================================
-// Tile kernel: one 8x8x8-cell block per workgroup, ONE THREAD PER TARGET, candidates staged in LDS.
+// Tile kernel: one 8x8x8-cell block per workgroup, candidates staged in LDS, FOUR LANES (a DPP quad) PER TARGET.
 //
-// Why a second kernel: the 8-lanes-per-target kernel above is VALU-issue-bound (every cross-lane insertion runs with
-// 1/8 of the wave doing useful work).  Targets of one block share their 3x3x3 neighbourhoods, so the 10x10x10-cell
-// region around the block is staged ONCE into LDS (coalesced row copies) and every lane then ranks its own target:
-//   pass 1  fp32 distances, running k smallest VALUES only (v_med3 chain, no payload)  ->  a proven upper bound on the
-//           exact k-th squared distance (see `kth_bound32`);
-//   pass 2  re-scan, queue the positions of the few candidates within that bound (per-lane queue in LDS);
-//   pass 3  exact fp64 metric + total order (d2, index) on the queued candidates only.
-// Targets that ring 1 cannot settle (k-th neighbour farther than the region guarantees, queue overflow, region larger
-// than the LDS budget) are appended to `todo` and finished by the group kernel.  fp32 records only (the fp32
-// pre-filter needs exact fp32 inputs).
+// Why a second kernel: the 8-lanes-per-target kernel above is VALU-issue-bound -- every step pays fp64 ranking and
+// cross-lane insertion with 1/8 of the wave doing useful work.  Targets of one block share their 3x3x3 neighbourhoods,
+// so the 10x10x10-cell region around the block is staged ONCE into LDS (coalesced row copies) and ranked from there:
+//   pass 1  each lane of a quad scans its share of the 27 cells (2 rows + 1 cell of the ninth row) in fp32 and keeps
+//           the K smallest VALUES only (v_med3 chain, every lane busy, no payload, no cross-lane traffic); the four
+//           sorted lists are merged with two bitonic DPP steps -> a proven upper bound on the exact k-th squared
+//           distance (see `kth_bound32`);
+//   pass 2  re-scan under that bound (now cells can be pruned), the few candidates within it go to the quad's queue;
+//   pass 3  exact fp64 metric on the queued candidates, ranked under the total order (d2, index) by all-pairs
+//           counting through DPP quad broadcasts; each survivor is written straight to its final slot.
+// Targets that ring 1 cannot settle (k-th neighbour farther than the region guarantees, more near-ties than the queue
+// holds, region larger than the LDS budget) are appended to `todo` and finished by the group kernel.  fp32 records
+// only (the fp32 pre-filter needs exact fp32 inputs).
+constexpr int TWG = 768;             // 12 waves = 192 quads per workgroup (one workgroup per CU: LDS-bound)
 constexpr int TILE_R = 10, TILE_CELLS = TILE_R * TILE_R * TILE_R;
 constexpr int TILE_CAP = 8448;       // records staged per tile (132 KB); a uniform rho = 8 region holds 8000 +- 90
-constexpr int TILE_Q = 32;           // queue entries per lane
+// queue entries per quad: room for the k survivors plus near-ties (LDS-limited at K = 32)
+template <int K> struct TileQ { static constexpr int CAP = K == 8 ? 16 : (K == 16 ? 32 : 48); };
+constexpr int TILE_QUADS = TWG / 4;
 
 __device__ inline float dist2_f32(float qx, float qy, float qz, const RecF& r) {
   const float dx = qx - r.x, dy = qy - r.y, dz = qz - r.z;
@@ -390,15 +396,41 @@ __device__ inline float dist2_f32(float qx, float qy, float qz, const RecF& r) {
 // D_k <= b*(1+2^-21), and every candidate with exact d2 <= D_k has d32 <= b*(1+2^-21)^2 < b*(1+2^-18).
 __device__ inline float kth_bound32(float b) { return b * 1.0000038146972656f + 1e-30f; }   // 1 + 2^-18, + denormal slack
 
+template <int CTRL>
+__device__ inline float dpp_f32(float v) { return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v))); }
+constexpr int DPP_QP_1032 = 0xB1;    // quad_perm [1,0,3,2]: partner lane ^ 1
+constexpr int DPP_QP_2301 = 0x4E;    // quad_perm [2,3,0,1]: partner lane ^ 2
+constexpr int DPP_QP_0000 = 0x00, DPP_QP_1111 = 0x55, DPP_QP_2222 = 0xAA, DPP_QP_3333 = 0xFF;
+
+// merge my ascending list with the partner lane's: afterwards both lanes hold the K smallest of the 2K values, ascending
+template <int K, int CTRL>
+__device__ inline void quad_merge_sorted(float (&l)[K]) {
+  float c[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) c[j] = fminf(l[j], dpp_f32<CTRL>(l[K - 1 - j]));   // bitonic: lowest K of the union
+#pragma unroll
+  for (int d = K / 2; d >= 1; d >>= 1) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if ((j & d) == 0) { const float lo = fminf(c[j], c[j + d]), hi = fmaxf(c[j], c[j + d]); c[j] = lo; c[j + d] = hi; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) l[j] = c[j];
+}
+
 template <int K>
-__global__ __launch_bounds__(WG, 1) void knn_tile_kernel(GridParams gp, const RecF* __restrict__ src, const uint32_t* __restrict__ cs,
-                                                      const RecF* __restrict__ tgt, const uint32_t* __restrict__ tblock_start, int k,
-                                                      uint32_t* __restrict__ out_idx, double* __restrict__ out_d2,
-                                                      uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_n) {
+__global__ __launch_bounds__(TWG, 1) void knn_tile_kernel(GridParams gp, const RecF* __restrict__ src, const uint32_t* __restrict__ cs,
+                                                        const RecF* __restrict__ tgt, const uint32_t* __restrict__ tblock_start, int k,
+                                                        uint32_t* __restrict__ out_idx, double* __restrict__ out_d2,
+                                                        uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_n) {
+  constexpr int NW = TWG / 64;
+  constexpr int TILE_QCAP = TileQ<K>::CAP;
   __shared__ __attribute__((aligned(16))) RecF lrec[TILE_CAP];
   __shared__ uint32_t lstart[TILE_CELLS + 8];
-  __shared__ __attribute__((aligned(16))) uint16_t queue[WG * TILE_Q];     // first 4000 bytes double as gstart[] during staging
-  __shared__ uint32_t wsum[4];
+  __shared__ __attribute__((aligned(16))) uint16_t queue[TILE_QUADS * TILE_QCAP];   // doubles as gstart[] during staging
+  __shared__ uint32_t qn[TILE_QUADS];
+  __shared__ uint32_t wsum[NW];
   uint32_t* gstart = reinterpret_cast<uint32_t*>(queue);
   static_assert(sizeof(queue) >= TILE_CELLS * sizeof(uint32_t), "gstart aliases the queue");
 
@@ -431,8 +463,14 @@ __global__ __launch_bounds__(WG, 1) void knn_tile_kernel(GridParams gp, const Re
       }
       sum += cnt[i];
     }
-    uint32_t tot;
-    uint32_t ex = block_excl_scan(sum, wsum, tot);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan(sum);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { const uint32_t ws = wsum[i]; if (i < w) off += ws; tot += ws; }
+    uint32_t ex = off + incl - sum;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = threadIdx.x * 4 + i;
@@ -440,62 +478,49 @@ __global__ __launch_bounds__(WG, 1) void knn_tile_kernel(GridParams gp, const Re
       ex += cnt[i];
     }
     if (threadIdx.x == 0) lstart[TILE_CELLS] = tot;
+    if (threadIdx.x < TILE_QUADS) qn[threadIdx.x] = 0;
   }
   __syncthreads();
   const uint32_t P = lstart[TILE_CELLS];
   if (P > (uint32_t)TILE_CAP) {                     // denser than the LDS budget: the group kernel takes the whole tile
-    for (uint32_t t = ts + threadIdx.x; t < te; t += WG) todo[atomicAdd(todo_n, 1u)] = t;
+    for (uint32_t t = ts + threadIdx.x; t < te; t += TWG) todo[atomicAdd(todo_n, 1u)] = t;
     return;
   }
   // ---- B: stage the region.  Cells x = 1..8 of a region row are one contiguous run in HBM and in LDS: a wave copies
   //         a row with two instructions (<= 128 records); the 200 halo cells (x = 0 and 9) are copied by 8-lane groups.
   //         With one workgroup per CU nothing else hides HBM latency, so every load of a batch is issued before the
-  //         first LDS store: 2 + 1 exposed latencies per tile instead of one per row.
+  //         first LDS store: two exposed latencies per tile instead of one per row.
   {
     const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(src);     // records move as raw 16-byte words
     uint4* l4 = reinterpret_cast<uint4*>(lrec);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int ROWS_PER_WAVE = TILE_R * TILE_R / (WG / 64);      // 25
-    constexpr int RB = 13;                                          // rows per batch
+    constexpr int NROWS = TILE_R * TILE_R;
+    constexpr int RB = (NROWS + NW - 1) / NW;                       // 9 rows per wave
+    uint4 t0[RB], t1[RB];
+    uint32_t la[RB], len[RB];
     bool long_rows = false;
 #pragma unroll
-    for (int b0 = 0; b0 < ROWS_PER_WAVE; b0 += RB) {
-      uint4 t0[RB], t1[RB];
-      uint32_t la[RB], len[RB];
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const int ri = (b0 + i < ROWS_PER_WAVE) ? b0 + i : ROWS_PER_WAVE - 1;
-        const int c1 = (w + ri * (WG / 64)) * TILE_R + 1;
-        la[i] = lstart[c1];
-        len[i] = (b0 + i < ROWS_PER_WAVE) ? lstart[c1 + 8] - la[i] : 0u;
-        const uint32_t ga = gstart[c1];
-        t0[i] = make_uint4(0, 0, 0, 0); t1[i] = make_uint4(0, 0, 0, 0);
-        if ((uint32_t)lane < len[i]) t0[i] = src4[ga + lane];
-        if ((uint32_t)lane + 64u < len[i]) t1[i] = src4[ga + lane + 64u];
-        long_rows |= len[i] > 128u;
-      }
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        if ((uint32_t)lane < len[i]) l4[la[i] + lane] = t0[i];
-        if ((uint32_t)lane + 64u < len[i]) l4[la[i] + lane + 64u] = t1[i];
-      }
-    }
-    if (long_rows) {                                                // very dense rows: the rest synchronously
-      for (int ri = 0; ri < ROWS_PER_WAVE; ++ri) {
-        const int c1 = (w + ri * (WG / 64)) * TILE_R + 1;
-        const uint32_t la = lstart[c1], len = lstart[c1 + 8] - la, ga = gstart[c1];
-        for (uint32_t p = lane + 128u; p < len; p += 64) l4[la + p] = src4[ga + p];
-      }
+    for (int i = 0; i < RB; ++i) {
+      const int rr = w + i * NW;
+      const int row = rr < NROWS ? rr : NROWS - 1;
+      const int c1 = row * TILE_R + 1;
+      la[i] = lstart[c1];
+      len[i] = rr < NROWS ? lstart[c1 + 8] - la[i] : 0u;
+      const uint32_t ga = gstart[c1];
+      t0[i] = make_uint4(0, 0, 0, 0); t1[i] = make_uint4(0, 0, 0, 0);
+      if ((uint32_t)lane < len[i]) t0[i] = src4[ga + lane];
+      if ((uint32_t)lane + 64u < len[i]) t1[i] = src4[ga + lane + 64u];
+      long_rows |= len[i] > 128u;
     }
     const int g8 = threadIdx.x >> 3, l8 = threadIdx.x & 7;
-    constexpr int NHALO = 2 * TILE_R * TILE_R;
-    constexpr int HC = (NHALO + WG / 8 - 1) / (WG / 8);             // 7 halo cells per 8-lane group
+    constexpr int NHALO = 2 * NROWS;
+    constexpr int HC = (NHALO + TWG / 8 - 1) / (TWG / 8);           // 3 halo cells per 8-lane group
     uint4 h0[HC], h1[HC];
     uint32_t hla[HC], hlen[HC];
     bool long_cells = false;
 #pragma unroll
     for (int i = 0; i < HC; ++i) {
-      const int hcr = g8 + i * (WG / 8);
+      const int hcr = g8 + i * (TWG / 8);
       const int hc = hcr < NHALO ? hcr : NHALO - 1;
       const int c = (hc >> 1) * TILE_R + ((hc & 1) ? TILE_R - 1 : 0);
       hla[i] = lstart[c];
@@ -507,24 +532,41 @@ __global__ __launch_bounds__(WG, 1) void knn_tile_kernel(GridParams gp, const Re
       long_cells |= hlen[i] > 16u;
     }
 #pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      if ((uint32_t)lane < len[i]) l4[la[i] + lane] = t0[i];
+      if ((uint32_t)lane + 64u < len[i]) l4[la[i] + lane + 64u] = t1[i];
+    }
+#pragma unroll
     for (int i = 0; i < HC; ++i) {
       if ((uint32_t)l8 < hlen[i]) l4[hla[i] + l8] = h0[i];
       if ((uint32_t)l8 + 8u < hlen[i]) l4[hla[i] + l8 + 8u] = h1[i];
     }
+    if (long_rows) {                                                // very dense rows: the rest synchronously
+      for (int row = w; row < NROWS; row += NW) {
+        const int c1 = row * TILE_R + 1;
+        const uint32_t a0 = lstart[c1], n0 = lstart[c1 + 8] - a0, ga = gstart[c1];
+        for (uint32_t p = lane + 128u; p < n0; p += 64) l4[a0 + p] = src4[ga + p];
+      }
+    }
     if (long_cells) {
-      for (int hc = g8; hc < NHALO; hc += WG / 8) {
+      for (int hc = g8; hc < NHALO; hc += TWG / 8) {
         const int c = (hc >> 1) * TILE_R + ((hc & 1) ? TILE_R - 1 : 0);
-        const uint32_t la = lstart[c], len = lstart[c + 1] - la, ga = gstart[c];
-        for (uint32_t p = l8 + 16u; p < len; p += 8) l4[la + p] = src4[ga + p];
+        const uint32_t a0 = lstart[c], n0 = lstart[c + 1] - a0, ga = gstart[c];
+        for (uint32_t p = l8 + 16u; p < n0; p += 8) l4[a0 + p] = src4[ga + p];
       }
     }
   }
   __syncthreads();                                  // gstart is dead from here on: the queue takes its place
 
-  // ---- C: one thread per target -------------------------------------------------------------------------------------
+  // ---- C: four lanes per target, 192 targets per round ----------------------------------------------------------------
   const double h2 = gp.h * gp.h;
-  for (uint32_t t = ts + threadIdx.x; t < te; t += WG) {
-    const RecF tr = tgt[t];
+  const int quad = threadIdx.x >> 2, ql = threadIdx.x & 3;
+  for (uint32_t base = ts; base < te; base += TILE_QUADS) {            // uniform trip count: barriers inside are legal
+    const uint32_t t = base + quad;
+    const bool active = t < te;                                        // whole quads are active or not
+    RecF tr;
+    tr.x = tr.y = tr.z = 0.f; tr.id = 0;
+    if (active) tr = tgt[t];
     const double q[3] = {(double)tr.x, (double)tr.y, (double)tr.z};
     double u[3];
     int cc[3];
@@ -533,39 +575,23 @@ __global__ __launch_bounds__(WG, 1) void knn_tile_kernel(GridParams gp, const Re
       u[a] = (q[a] - gp.bbmin[a]) * gp.inv_h;
       cc[a] = (int)fmin(fmax(u[a], 0.0), (double)(gp.dim[a] - 1));
     }
-    const int rx = cc[0] - ox, ry = cc[1] - oy, rz = cc[2] - oz;       // region coordinates of the target's cell, in [1, 8]
-    // squared lower bound (cell units) from the target to cell interval [lo, hi] along axis a
-    auto gap = [&](int a, int lo, int hi) -> double {
-      const double g = fmax((double)lo - u[a], u[a] - (double)(hi + 1)) - PT_CELL_EPS;
-      return fmax(g, 0.0);
-    };
-    // LDS range of the cells of row r that may hold a point with d2 <= lim (lim in world units, +inf = everything)
-    auto row_range = [&](int r, double lim, uint32_t& pa, uint32_t& pe) {
-      pa = pe = 0;
-      const int y = cc[1] + row_dy(r), z = cc[2] + row_dz(r);
-      const double gy = gap(1, y, y), gz = gap(2, z, z);
-      const double s2 = gy * gy + gz * gz;
-      if (s2 * h2 > lim) return;
-      const int c0 = ((rz + row_dz(r)) * TILE_R + (ry + row_dy(r))) * TILE_R + (rx - 1);
-      int ja = 0, jb = 2;
-      { const double g = gap(0, cc[0] - 1, cc[0] - 1); if ((g * g + s2) * h2 > lim) ja = 1; }
-      { const double g = gap(0, cc[0] + 1, cc[0] + 1); if ((g * g + s2) * h2 > lim) jb = 1; }
-      pa = lstart[c0 + ja];
-      pe = lstart[c0 + jb + 1];
-    };
+    const int rx = active ? cc[0] - ox : 1, ry = active ? cc[1] - oy : 1, rz = active ? cc[2] - oz : 1;   // in [1, 8]
+    // this lane's share of ring 1: rows ql and ql+4 (3 cells each) and, for lanes 1..3, cell ql-1 of row 8
+    const int rowA = ql, rowB = ql + 4;
+    const int cA = ((rz + row_dz(rowA)) * TILE_R + (ry + row_dy(rowA))) * TILE_R + (rx - 1);
+    const int cB = ((rz + row_dz(rowB)) * TILE_R + (ry + row_dy(rowB))) * TILE_R + (rx - 1);
+    const int cC = ((rz + row_dz(8)) * TILE_R + (ry + row_dy(8))) * TILE_R + (rx - 1) + (ql > 0 ? ql - 1 : 0);
+    uint32_t sA[4], sB[4], sC[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sA[j] = lstart[cA + j]; sB[j] = lstart[cB + j]; }
+    sC[0] = lstart[cC]; sC[1] = (ql > 0) ? lstart[cC + 1] : sC[0];
 
-    // pass 1: k smallest fp32 distances (values only)
+    // ---- pass 1: K smallest fp32 distances of my share (values only) ----
     float l32[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) l32[j] = INFINITY;
-#pragma unroll 1
-    for (int r = 0; r < 9; ++r) {
-      uint32_t pa, pe;
-      float kv = l32[0];
-#pragma unroll
-      for (int j = 1; j < K; ++j) kv = (j == k - 1) ? l32[j] : kv;
-      row_range(r, (double)kth_bound32(kv), pa, pe);
-      for (uint32_t p = pa; p < pe; p += 4) {        // 4 LDS reads in flight per lane (one wave per SIMD: ILP is all there is)
+    auto scan1 = [&](uint32_t pa, uint32_t pe) {
+      for (uint32_t p = pa; p < pe; p += 4) {          // 4 LDS reads in flight per lane
         float x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -581,59 +607,103 @@ __global__ __launch_bounds__(WG, 1) void knn_tile_kernel(GridParams gp, const Re
           for (int j = 1; j < K; ++j) { const float cur = l32[j]; l32[j] = __builtin_amdgcn_fmed3f(x[i], prev, cur); prev = cur; }
         }
       }
+    };
+    if (active) {
+      scan1(sA[0], sA[3]);
+      scan1(sB[0], sB[3]);
+      scan1(sC[0], sC[1]);
     }
-    // pass 2: queue the candidates within the proven bound
-    float kv2 = l32[0];
+    // the quad's K smallest: two bitonic merges through DPP (all lanes of the wave take part: no divergence here)
+    quad_merge_sorted<K, DPP_QP_1032>(l32);
+    quad_merge_sorted<K, DPP_QP_2301>(l32);
+    float kv = l32[0];
 #pragma unroll
-    for (int j = 1; j < K; ++j) kv2 = (j == k - 1) ? l32[j] : kv2;
-    const float thr = kth_bound32(kv2);
-    uint32_t nq = 0;
+    for (int j = 1; j < K; ++j) kv = (j == k - 1) ? l32[j] : kv;
+    const float thr = kth_bound32(kv);
+    const double lim = (double)thr;
+
+    // ---- pass 2: re-scan under the bound, queue what is within it ----
+    auto gap = [&](int a, int lo, int hi) -> double {
+      const double g = fmax((double)lo - u[a], u[a] - (double)(hi + 1)) - PT_CELL_EPS;
+      return fmax(g, 0.0);
+    };
     bool overflow = false;
-#pragma unroll 1
-    for (int r = 0; r < 9; ++r) {
-      uint32_t pa, pe;
-      row_range(r, (double)thr, pa, pe);
+    auto scan2 = [&](uint32_t pa, uint32_t pe) {
       for (uint32_t p = pa; p < pe; p += 4) {
         float x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const uint32_t pi = min(p + i, pe - 1);
           x[i] = dist2_f32(tr.x, tr.y, tr.z, lrec[pi]);
-          if (p + i >= pe) x[i] = INFINITY;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (p + i < pe && x[i] <= thr) {            // (thr may be +inf: the padding lanes must not pass)
-            if (nq < (uint32_t)TILE_Q) queue[nq * WG + threadIdx.x] = (uint16_t)(p + i); else overflow = true;
-            ++nq;
+            const uint32_t pos = atomicAdd(&qn[quad], 1u);
+            if (pos < (uint32_t)TILE_QCAP) queue[quad * TILE_QCAP + pos] = (uint16_t)(p + i); else overflow = true;
           }
         }
       }
-    }
-    // pass 3: exact metric and total order on the queued candidates
-    double ld[K];
-    uint32_t li[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) { ld[j] = INFINITY; li[j] = PT_NOIDX_U; }
-    const uint32_t nqc = min(nq, (uint32_t)TILE_Q);
-    for (uint32_t e = 0; e < nqc; ++e) {
-      const RecF r = lrec[queue[e * WG + threadIdx.x]];
-      const double d = dist2(q, r);
-      bool c[K];
-#pragma unroll
-      for (int j = 0; j < K; ++j) c[j] = key_lt(d, r.id, ld[j], li[j]);
-#pragma unroll
-      for (int j = K - 1; j >= 1; --j) {
-        ld[j] = c[j - 1] ? ld[j - 1] : (c[j] ? d : ld[j]);
-        li[j] = c[j - 1] ? li[j - 1] : (c[j] ? r.id : li[j]);
+    };
+    auto scan2_row = [&](int r, const uint32_t (&s4)[4]) {
+      const int y = cc[1] + row_dy(r), z = cc[2] + row_dz(r);
+      const double gy = gap(1, y, y), gz = gap(2, z, z);
+      const double s2 = gy * gy + gz * gz;
+      if (s2 * h2 > lim) return;
+      int ja = 0, jb = 2;
+      { const double g = gap(0, cc[0] - 1, cc[0] - 1); if ((g * g + s2) * h2 > lim) ja = 1; }
+      { const double g = gap(0, cc[0] + 1, cc[0] + 1); if ((g * g + s2) * h2 > lim) jb = 1; }
+      scan2(ja == 0 ? s4[0] : s4[1], jb == 2 ? s4[3] : s4[2]);
+    };
+    if (active) {
+      scan2_row(rowA, sA);
+      scan2_row(rowB, sB);
+      if (ql > 0) {
+        const int y = cc[1] + row_dy(8), z = cc[2] + row_dz(8), x = cc[0] - 1 + (ql - 1);
+        const double gx = gap(0, x, x), gy = gap(1, y, y), gz = gap(2, z, z);
+        if ((gx * gx + gy * gy + gz * gz) * h2 <= lim) scan2(sC[0], sC[1]);
       }
-      ld[0] = c[0] ? d : ld[0];
-      li[0] = c[0] ? r.id : li[0];
     }
-    // is ring 1 enough?  (same face test as the group kernel)
-    double kd = ld[0];
+    __syncthreads();                                   // the quad's queue is complete (and visible) past this point
+
+    // ---- pass 3: exact metric, ranking by all-pairs counting inside the quad ----
+    const uint32_t nq = qn[quad];
+    overflow = overflow || nq > (uint32_t)TILE_QCAP;
+    // (any lane's overflow flag must reach the whole quad)
+    overflow = (__ballot(overflow) >> ((threadIdx.x & 63) & ~3)) & 0xFull;
+    double od[TILE_QCAP / 4];
+    uint32_t oi[TILE_QCAP / 4];
+    int rk[TILE_QCAP / 4];
 #pragma unroll
-    for (int j = 1; j < K; ++j) if (j == k - 1) kd = ld[j];
+    for (int j = 0; j < TILE_QCAP / 4; ++j) {          // my entries: ql, ql+4, ...
+      const uint32_t e = (uint32_t)(4 * j + ql);
+      od[j] = INFINITY; oi[j] = PT_NOIDX_U; rk[j] = 0;
+      if (e < nq && e < (uint32_t)TILE_QCAP) {
+        const RecF r = lrec[queue[quad * TILE_QCAP + e]];
+        od[j] = dist2(q, r);
+        oi[j] = r.id;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TILE_QCAP / 4; ++j) {          // round j: the four lanes' j-th entries visit every lane
+      if ((uint32_t)(4 * j) < nq) {                    // quad-uniform
+        const double b0 = dpp_f64<DPP_QP_0000>(od[j]), b1 = dpp_f64<DPP_QP_1111>(od[j]), b2 = dpp_f64<DPP_QP_2222>(od[j]),
+                     b3 = dpp_f64<DPP_QP_3333>(od[j]);
+        const uint32_t i0 = dpp_u32<DPP_QP_0000>(oi[j]), i1 = dpp_u32<DPP_QP_1111>(oi[j]), i2 = dpp_u32<DPP_QP_2222>(oi[j]),
+                       i3 = dpp_u32<DPP_QP_3333>(oi[j]);
+#pragma unroll
+        for (int m = 0; m < TILE_QCAP / 4; ++m) {
+          rk[m] += (int)key_lt(b0, i0, od[m], oi[m]) + (int)key_lt(b1, i1, od[m], oi[m]) + (int)key_lt(b2, i2, od[m], oi[m]) +
+                   (int)key_lt(b3, i3, od[m], oi[m]);
+        }
+      }
+    }
+    // exact k-th squared distance of ring 1 (rank k-1), known to one lane -> quad minimum
+    double kd = INFINITY;
+#pragma unroll
+    for (int j = 0; j < TILE_QCAP / 4; ++j) if (oi[j] != PT_NOIDX_U && rk[j] == k - 1) kd = od[j];
+    kd = fmin(kd, dpp_f64<DPP_QP_1032>(kd));
+    kd = fmin(kd, dpp_f64<DPP_QP_2301>(kd));
     bool covered = true;
     double dout = INFINITY;
 #pragma unroll
@@ -644,14 +714,20 @@ __global__ __launch_bounds__(WG, 1) void knn_tile_kernel(GridParams gp, const Re
     }
     dout = fmax(dout - PT_CELL_EPS, 0.0);
     const bool done = !overflow && (covered || dout * dout * h2 > kd);
-    if (done) {
-      const size_t row = (size_t)tr.id * (size_t)k;
+    if (active) {
+      if (done) {
+        const size_t row = (size_t)tr.id * (size_t)k;
 #pragma unroll
-      for (int j = 0; j < K; ++j)
-        if (j < k) { out_idx[row + j] = li[j]; if (out_d2) out_d2[row + j] = ld[j]; }
-    } else {
-      todo[atomicAdd(todo_n, 1u)] = t;
+        for (int j = 0; j < TILE_QCAP / 4; ++j)
+          if (oi[j] != PT_NOIDX_U && rk[j] < k) { out_idx[row + rk[j]] = oi[j]; if (out_d2) out_d2[row + rk[j]] = od[j]; }
+        for (uint32_t sl = nq + ql; sl < (uint32_t)k; sl += 4) { out_idx[row + sl] = PT_NOIDX_U; if (out_d2) out_d2[row + sl] = INFINITY; }
+      } else if (ql == 0) {
+        todo[atomicAdd(todo_n, 1u)] = t;
+      }
     }
+    __syncthreads();
+    if (threadIdx.x < TILE_QUADS) qn[threadIdx.x] = 0;
+    __syncthreads();
   }
 }
 
@@ -725,11 +801,11 @@ void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* c
                         uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, hipStream_t s) {
   const uint32_t nb = (uint32_t)gp.nblocks;
   if (k <= 8)
-    hipLaunchKernelGGL(knn_tile_kernel<8>, dim3(nb), dim3(WG), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n);
+    hipLaunchKernelGGL(knn_tile_kernel<8>, dim3(nb), dim3(TWG), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n);
   else if (k <= 16)
-    hipLaunchKernelGGL(knn_tile_kernel<16>, dim3(nb), dim3(WG), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n);
+    hipLaunchKernelGGL(knn_tile_kernel<16>, dim3(nb), dim3(TWG), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n);
   else
-    hipLaunchKernelGGL(knn_tile_kernel<32>, dim3(nb), dim3(WG), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n);
+    hipLaunchKernelGGL(knn_tile_kernel<32>, dim3(nb), dim3(TWG), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n);
 }
 
 void pt_launch_merge(const uint32_t* idx_lists, const double* d2_lists, int g, uint32_t m, int k, uint32_t* idx_out, double* d2_out,

@@ -18,4 +18,4 @@ for name in names:
             torch.cuda.synchronize(); dt = time.time() - t
             st = p.stats()
             print(name, "wall %.2f ms" % (dt * 1e3), "build %.3f tsort %.3f knn %.3f blend %.3f" % (st["ms_build"], st["ms_sort_targets"], st["ms_query"], st["ms_blend"]),
-                  "kernels", [round(v, 3) for v in st["ms_kernel"]], "grid", st["grid_dim"], "GB", round(st["device_bytes"] / 1e9, 2), flush=True)
+                  "kernels", [round(v, 3) for v in st["ms_kernel"]], "leftover", st["n_leftover"], "grid", st["grid_dim"], "GB", round(st["device_bytes"] / 1e9, 2), flush=True)
