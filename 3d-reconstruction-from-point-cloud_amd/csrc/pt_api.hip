@@ -53,6 +53,7 @@ struct pt_ctx {
   int tgt_type = -1;
   uint64_t m = 0;
   DevBuf t_xyz, t_gidx, trec, trec_tmp;
+  DevBuf x_xyz;                // transient targets of pt_query_soa / _aos / _bounded_dev (resident targets stay untouched)
   bool t_has_gidx = false;
   SortTables ttb{};
   DevBuf ttb_mem;
@@ -238,20 +239,20 @@ int copy_in(pt_ctx* c, void* dst, const void* src, size_t bytes, int on_device) 
 }
 
 // sort the resident targets into cell order and run the k-NN kernel
-int query_resident(pt_ctx* c, int k, const double* bound2_dev, uint32_t* idx_dev, double* d2_dev) {
+int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const double* bound2_dev, uint32_t* idx_dev, double* d2_dev) {
   if (!c->built) return fail(c, PT_ERR_STATE, "query before build");
   if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k = %d out of range [1, %d]", k, PT_MAX_K);
-  if (c->tgt_type != c->src_type) return fail(c, PT_ERR_UNSUPPORTED, "target xyz type %d differs from the source cloud's %d", c->tgt_type, c->src_type);
-  if (!idx_dev && c->m) return fail(c, PT_ERR_ARG, "idx output is null");
+  if (ttype != c->src_type) return fail(c, PT_ERR_UNSUPPORTED, "target xyz type %d differs from the source cloud's %d", ttype, c->src_type);
+  if (!idx_dev && tm) return fail(c, PT_ERR_ARG, "idx output is null");
   HIPCHK(c, hipSetDevice(c->device));
-  const uint32_t m = (uint32_t)c->m;
-  RES(c, c->trec, std::max<size_t>(m, 1) * recsize(c->tgt_type));
-  RES(c, c->trec_tmp, std::max<size_t>(m, 1) * recsize(c->tgt_type));
+  const uint32_t m = (uint32_t)tm;
+  RES(c, c->trec, std::max<size_t>(m, 1) * recsize(ttype));
+  RES(c, c->trec_tmp, std::max<size_t>(m, 1) * recsize(ttype));
   RES(c, c->todo, std::max<size_t>(m, 1) * sizeof(uint32_t));
-  { int r = make_tables(c, c->ttb_mem, c->ttb, (uint32_t)c->gp.nblocks, m, recsize(c->tgt_type)); if (r != PT_OK) return r; }
+  { int r = make_tables(c, c->ttb_mem, c->ttb, (uint32_t)c->gp.nblocks, m, recsize(ttype)); if (r != PT_OK) return r; }
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  if (c->tgt_type == PT_F32) {
-    const float* x = (const float*)c->t_xyz.p;
+  if (ttype == PT_F32) {
+    const float* x = (const float*)txyz;
     pt_launch_grid_sort<float, RecF>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecF*)c->trec.p, (RecF*)c->trec_tmp.p, nullptr, c->ttb, c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (c->tile && !bound2_dev && m) {
@@ -267,7 +268,7 @@ int query_resident(pt_ctx* c, int k, const double* bound2_dev, uint32_t* idx_dev
                           nullptr, nullptr, c->stream);
     }
   } else {
-    const double* x = (const double*)c->t_xyz.p;
+    const double* x = (const double*)txyz;
     pt_launch_grid_sort<double, RecD>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecD*)c->trec.p, (RecD*)c->trec_tmp.p, nullptr, c->ttb, c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecD*)c->trec.p, m, k, bound2_dev, idx_dev, d2_dev,
@@ -288,21 +289,18 @@ int query_resident(pt_ctx* c, int k, const double* bound2_dev, uint32_t* idx_dev
     c->st.ms_query = b;
     c->st.ms_kernel[6] = a;
     c->st.ms_kernel[7] = b;
-    c->st.n_leftover = (c->tile && !bound2_dev && m && c->tgt_type == PT_F32) ? c->h_counter[4] : 0;
+    c->st.n_leftover = (c->tile && !bound2_dev && m && ttype == PT_F32) ? c->h_counter[4] : 0;
   }
   return PT_OK;
 }
 
-int load_targets(pt_ctx* c, const void* xyz, int xyz_type, uint64_t m, int on_device) {
+// copy caller targets into the transient buffer (resident targets are not touched)
+int load_transient(pt_ctx* c, const void* xyz, int xyz_type, uint64_t m, int on_device) {
   if (xyz_type != PT_F32 && xyz_type != PT_F64) return fail(c, PT_ERR_UNSUPPORTED, "xyz_type %d not supported yet (f32 and f64 are)", xyz_type);
   if (m && !xyz) return fail(c, PT_ERR_ARG, "target xyz is null");
   { int r = check_n(c, m, "m"); if (r) return r; }
-  RES(c, c->t_xyz, std::max<uint64_t>(m, 1) * 3 * tsize(xyz_type));
-  { int r = copy_in(c, c->t_xyz.p, xyz, m * 3 * tsize(xyz_type), on_device); if (r) return r; }
-  c->tgt_type = xyz_type;
-  c->m = m;
-  c->t_has_gidx = false;
-  return PT_OK;
+  RES(c, c->x_xyz, std::max<uint64_t>(m, 1) * 3 * tsize(xyz_type));
+  return copy_in(c, c->x_xyz.p, xyz, m * 3 * tsize(xyz_type), on_device);
 }
 
 }  // namespace
@@ -341,7 +339,7 @@ void pt_ctx_destroy(pt_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in_xyz, &c->in_gidx, &c->attr, &c->rec, &c->rec_tmp, &c->cell_start, &c->stb_mem, &c->t_xyz, &c->t_gidx, &c->trec,
-                   &c->trec_tmp, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo};
+                   &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo};
   for (DevBuf* b : all) release(c, *b);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);
@@ -353,7 +351,7 @@ void pt_ctx_destroy(pt_ctx* c) {
 
 int pt_set_stream(pt_ctx* c, void* hip_stream) {
   if (!c) return PT_ERR_ARG;
-  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  c->stream = (hipStream_t)hip_stream;    // NULL is HIP's default stream (what torch uses unless told otherwise)
   return PT_OK;
 }
 
@@ -362,6 +360,7 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!strcmp(name, "rho")) { if (!(value >= 0.25 && value <= 4096)) return fail(c, PT_ERR_ARG, "rho out of range"); c->rho = value; return PT_OK; }
   if (!strcmp(name, "sync")) { c->sync = value != 0; return PT_OK; }
   if (!strcmp(name, "tile")) { c->tile = value != 0; return PT_OK; }
+  if (!strcmp(name, "own_stream")) { if (value != 0) c->stream = c->own_stream; return PT_OK; }
   return fail(c, PT_ERR_ARG, "unknown parameter '%s'", name);
 }
 
@@ -505,7 +504,7 @@ int pt_targets_synth(pt_ctx* c, uint64_t m_total, uint64_t seed, int dist, int x
 int pt_query_resident(pt_ctx* c, int k, uint32_t* idx_dev, double* d2_dev_or_null) {
   if (!c) return PT_ERR_ARG;
   if (c->tgt_type < 0) return fail(c, PT_ERR_STATE, "no resident targets");
-  return query_resident(c, k, nullptr, idx_dev, d2_dev_or_null);
+  return run_query(c, c->t_xyz.p, c->tgt_type, c->m, k, nullptr, idx_dev, d2_dev_or_null);
 }
 
 int pt_resident_target_ids(pt_ctx* c, uint32_t* ids_dev) {
@@ -528,11 +527,11 @@ int pt_query_soa(pt_ctx* c, const void* xyz, int xyz_type, uint64_t m, int k, in
   if (!c->built) return fail(c, PT_ERR_STATE, "query before build");
   if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k = %d out of range [1, %d]", k, PT_MAX_K);
   if (m && !idx) return fail(c, PT_ERR_ARG, "idx output is null");
-  { int r = load_targets(c, xyz, xyz_type, m, on_device); if (r) return r; }
-  if (on_device) return query_resident(c, k, nullptr, idx, d2_or_null);
+  { int r = load_transient(c, xyz, xyz_type, m, on_device); if (r) return r; }
+  if (on_device) return run_query(c, c->x_xyz.p, xyz_type, m, k, nullptr, idx, d2_or_null);
   RES(c, c->q_idx, std::max<uint64_t>(m, 1) * k * sizeof(uint32_t));
   if (d2_or_null) RES(c, c->q_d2, std::max<uint64_t>(m, 1) * k * sizeof(double));
-  { int r = query_resident(c, k, nullptr, (uint32_t*)c->q_idx.p, d2_or_null ? (double*)c->q_d2.p : nullptr); if (r) return r; }
+  { int r = run_query(c, c->x_xyz.p, xyz_type, m, k, nullptr, (uint32_t*)c->q_idx.p, d2_or_null ? (double*)c->q_d2.p : nullptr); if (r) return r; }
   if (m) {
     HIPCHK(c, hipMemcpyAsync(idx, c->q_idx.p, m * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     if (d2_or_null) HIPCHK(c, hipMemcpyAsync(d2_or_null, c->q_d2.p, m * k * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -548,14 +547,13 @@ int pt_query_aos(pt_ctx* c, const pt_point* targets, uint64_t m, int k, uint32_t
   { int r = check_n(c, m, "m"); if (r) return r; }
   HIPCHK(c, hipSetDevice(c->device));
   RES(c, c->aos_stage, std::max<uint64_t>(m, 1) * sizeof(pt_point));
-  RES(c, c->t_xyz, std::max<uint64_t>(m, 1) * 3 * sizeof(double));
+  RES(c, c->x_xyz, std::max<uint64_t>(m, 1) * 3 * sizeof(double));
   { int r = copy_in(c, c->aos_stage.p, targets, m * sizeof(pt_point), 0); if (r) return r; }
-  double* x = (double*)c->t_xyz.p;
+  double* x = (double*)c->x_xyz.p;
   pt_launch_aos_split(c->aos_stage.p, (uint32_t)m, x, x + m, x + 2 * m, nullptr, c->stream);
-  c->tgt_type = PT_F64; c->m = m; c->t_has_gidx = false;
   RES(c, c->q_idx, std::max<uint64_t>(m, 1) * k * sizeof(uint32_t));
   if (d2_or_null) RES(c, c->q_d2, std::max<uint64_t>(m, 1) * k * sizeof(double));
-  { int r = query_resident(c, k, nullptr, (uint32_t*)c->q_idx.p, d2_or_null ? (double*)c->q_d2.p : nullptr); if (r) return r; }
+  { int r = run_query(c, c->x_xyz.p, PT_F64, m, k, nullptr, (uint32_t*)c->q_idx.p, d2_or_null ? (double*)c->q_d2.p : nullptr); if (r) return r; }
   if (m) {
     HIPCHK(c, hipMemcpyAsync(idx, c->q_idx.p, m * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     if (d2_or_null) HIPCHK(c, hipMemcpyAsync(d2_or_null, c->q_d2.p, m * k * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -567,8 +565,9 @@ int pt_query_aos(pt_ctx* c, const pt_point* targets, uint64_t m, int k, uint32_t
 int pt_query_bounded_dev(pt_ctx* c, const void* xyz_dev, int xyz_type, const double* bound2_dev, uint64_t m, int k, uint32_t* idx_dev,
                          double* d2_dev) {
   if (!c) return PT_ERR_ARG;
-  { int r = load_targets(c, xyz_dev, xyz_type, m, 1); if (r) return r; }
-  return query_resident(c, k, bound2_dev, idx_dev, d2_dev);
+  if (!c->built) return fail(c, PT_ERR_STATE, "query before build");
+  { int r = load_transient(c, xyz_dev, xyz_type, m, 1); if (r) return r; }
+  return run_query(c, c->x_xyz.p, xyz_type, m, k, bound2_dev, idx_dev, d2_dev);
 }
 
 // ---- blend / PCA -----------------------------------------------------------------------------------

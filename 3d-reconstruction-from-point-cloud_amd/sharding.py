@@ -46,6 +46,20 @@ class TorchDistComm:
         return int(t.item())
 
 
+class HostStagedComm(TorchDistComm):
+    """Same interface over a backend that cannot move device tensors (gloo): collectives are staged through host
+    memory.  Used to rehearse the multi-rank bench flow with several ranks sharing ONE GPU (RCCL refuses that)."""
+
+    def all_gather(self, t):
+        h = t.detach().cpu().contiguous()
+        out = torch.empty((self.world * h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
+        self._d.all_gather_into_tensor(out, h, group=self.group)
+        return out.view((self.world,) + tuple(h.shape)).to(t.device)
+
+    def max_int(self, v, device):
+        return super().max_int(v, "cpu")
+
+
 class SingleComm:
     """world_size 1 (no exchange ever happens)."""
     rank, world = 0, 1

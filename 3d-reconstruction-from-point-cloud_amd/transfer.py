@@ -11,6 +11,7 @@ GPU; nothing here computes neighbours on the CPU.
 """
 import ctypes as C
 import math
+import sys
 
 import numpy as np
 
@@ -83,6 +84,13 @@ class PointsTransfer:
 
     def set_stream(self, hip_stream):
         self._chk(self._L.pt_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def _adopt_torch_stream(self):
+        """Device-pointer entry points are fed by torch tensors: run on torch's CURRENT stream so that the kernels
+        queue behind whatever produced those tensors (the context's own stream is non-blocking and would race)."""
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available():
+            self._chk(self._L.pt_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     def synchronize(self):
         self._chk(self._L.pt_synchronize(self._h))
@@ -157,18 +165,23 @@ class PointsTransfer:
         self._chk(self._L.pt_targets_synth(self._h, m_total, seed, dist, xyz_type, slab_axis, slab_lo, slab_hi))
 
     def query_resident_dev(self, k, idx_dev, d2_dev=None):
+        self._adopt_torch_stream()
         self._chk(self._L.pt_query_resident(self._h, k, _ptr(idx_dev), _ptr(d2_dev)))
 
     def query_dev(self, xyz_dev, xyz_type, m, k, idx_dev, d2_dev=None):
+        self._adopt_torch_stream()
         self._chk(self._L.pt_query_soa(self._h, _ptr(xyz_dev), xyz_type, m, k, 1, _ptr(idx_dev), _ptr(d2_dev)))
 
     def query_bounded_dev(self, xyz_dev, xyz_type, bound2_dev, m, k, idx_dev, d2_dev):
+        self._adopt_torch_stream()
         self._chk(self._L.pt_query_bounded_dev(self._h, _ptr(xyz_dev), xyz_type, _ptr(bound2_dev), m, k, _ptr(idx_dev), _ptr(d2_dev)))
 
     def resident_target_ids_dev(self, ids_dev):
+        self._adopt_torch_stream()
         self._chk(self._L.pt_resident_target_ids(self._h, _ptr(ids_dev)))
 
     def resident_target_xyz_dev(self, xyz_dev):
+        self._adopt_torch_stream()
         self._chk(self._L.pt_resident_target_xyz(self._h, _ptr(xyz_dev)))
 
     # -- blend / PCA ----------------------------------------------------------------------------
@@ -182,6 +195,7 @@ class PointsTransfer:
         return rgb, nrm
 
     def blend_dev(self, idx_dev, d2_dev, m, k, mode, rgb_out_dev, nrm_out_dev):
+        self._adopt_torch_stream()
         self._chk(self._L.pt_blend_dev(self._h, _ptr(idx_dev), _ptr(d2_dev), m, k, mode, _ptr(rgb_out_dev), _ptr(nrm_out_dev)))
 
     def pca_normals(self, idx):
@@ -192,13 +206,16 @@ class PointsTransfer:
         return out
 
     def pca_normals_dev(self, idx_dev, m, k, nrm_out_dev):
+        self._adopt_torch_stream()
         self._chk(self._L.pt_pca_normals_dev(self._h, _ptr(idx_dev), m, k, _ptr(nrm_out_dev)))
 
     # -- multi-GPU helpers ---------------------------------------------------------
     def merge_candidates_dev(self, idx_lists_dev, d2_lists_dev, g, m, k, idx_out_dev, d2_out_dev):
+        self._adopt_torch_stream()
         self._chk(self._L.pt_merge_candidates_dev(self._h, _ptr(idx_lists_dev), _ptr(d2_lists_dev), g, m, k, _ptr(idx_out_dev), _ptr(d2_out_dev)))
 
     def slab_need_dev(self, tgt_xyz_dev, xyz_type, d2_dev, m, k, slab_axis, slab_bounds, my_slab, need_dev):
+        self._adopt_torch_stream()
         b = np.ascontiguousarray(slab_bounds, np.float64)
         g = b.shape[0] - 1
         self._chk(self._L.pt_slab_need_dev(self._h, _ptr(tgt_xyz_dev), xyz_type, _ptr(d2_dev), m, k, slab_axis, _ptr(b), g, my_slab, _ptr(need_dev)))

@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal only: ranks may share one GPU, collectives staged through host memory")
+    ap.add_argument("--n", type=int, default=0, help="override the workload's source count (rehearsals)")
+    ap.add_argument("--m", type=int, default=0, help="override the workload's target count (rehearsals)")
     args = ap.parse_args()
 
     import torch
@@ -99,16 +103,26 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-        comm = sharding.TorchDistComm()
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+            comm = sharding.HostStagedComm()
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+            comm = sharding.TorchDistComm()
     else:
         comm = sharding.SingleComm()
 
     n_total, m_total, k, seed = WORKLOADS[args.workload]
+    if args.n:
+        n_total = args.n
+    if args.m:
+        m_total = args.m
     axis = 0
     bounds = sharding.uniform_slab_bounds(world)
     pt = pkg.PointsTransfer(device=local_rank)
@@ -134,15 +148,16 @@ def main():
     def step(record):
         pt.rebuild()
         pt.query_resident_dev(k, idx, d2)
+        st = pt.stats() if record else None       # HIP-event times of the build + home search, on the stream they ran on
         xs = sharding.exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds)
         pt.blend_dev(idx, d2, m_loc, k, pkg.BLEND_MEAN, rgb, nrm)
         if record:
-            st = pt.stats()          # HIP-event times of this step's launches, on the stream they ran on
             for i in range(8):
                 kms[i] += st["ms_kernel"][i]
             phase["build"] += st["ms_build"]; phase["target_sort"] += st["ms_sort_targets"]
-            phase["knn"] += st["ms_query"]; phase["blend"] += st["ms_blend"]
+            phase["knn"] += st["ms_query"]; phase["blend"] += pt.stats()["ms_blend"]
             xstats.update(xs)
+            xstats["tile_leftover"] = st["n_leftover"]
 
     def fence():
         torch.cuda.synchronize()
@@ -159,7 +174,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -180,7 +195,7 @@ def main():
             "config": {"workload": "%s: %d-point source / %d targets / k=%d, uniform fp32 xyz in the unit cube, generator seed 0x%X"
                                    % (args.workload, n_total, m_total, k, seed),
                        "step": "grid build + target binning + k-NN + slab exchange/merge + mean blend, inputs resident in HBM",
-                       "parallelism": "slab%d" % world if world > 1 else "single"},
+                       "parallelism": "slab%d" % world if world > 1 else "single", "backend": args.backend if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "alg_bytes_per_launch": alg, "avg_launch_ms": kavg[dom]},

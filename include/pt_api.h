@@ -89,8 +89,9 @@ typedef struct pt_stats_t {
 /* device_ids[0] is the GPU this context runs on (one process per GPU); n_devices must be 1. */
 int  pt_ctx_create(pt_ctx** out, const int* device_ids, int n_devices);
 void pt_ctx_destroy(pt_ctx*);
-/* Plumbing: run all work of this context on the caller's hipStream_t (e.g. torch's current
- * stream).  NULL = the context's own stream. */
+/* Plumbing: run all work of this context on the caller's hipStream_t (e.g. torch's current stream), so that
+ * kernels queue behind whatever produced the device buffers handed in.  NULL = HIP's default stream;
+ * pt_set_param(ctx, "own_stream", 1) returns to the context's own (non-blocking) stream. */
 int  pt_set_stream(pt_ctx*, void* hip_stream);
 /* Tunables: "rho" (target points per grid cell, default 8), "sync" (1 = every call blocks until
  * the GPU is done, default 1; 0 = _dev calls only enqueue), "tile" (1 = tile kernel + group kernel for its

@@ -98,6 +98,31 @@ def test_device_generator_matches_oracle(pkg, oracle):
         assert np.abs(rgb.cpu().numpy() - rc).max() / 255 <= TOL and np.abs(nrm.cpu().numpy() - rn).max() <= TOL
 
 
+def test_transient_queries_leave_resident_targets_alone(pkg, oracle):
+    import torch
+    n, m, k, seed = 50000, 4000, 8, 5
+    with pkg.PointsTransfer(device=0) as p:
+        p.build_synth(n, seed)
+        p.targets_synth(m, seed)
+        a_i = torch.empty((m, k), dtype=torch.int32, device="cuda"); a_d = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        p.query_resident_dev(k, a_i, a_d)
+        other = oracle.synth_xyz(99, 1, 777)
+        p.query(other, k)                                              # host targets
+        ox = torch.from_numpy(other).cuda()
+        bi = torch.empty((777, k), dtype=torch.int32, device="cuda"); bd = torch.empty((777, k), dtype=torch.float64, device="cuda")
+        p.query_bounded_dev(ox, pkg.F32, torch.full((777,), 1e-3, dtype=torch.float64, device="cuda"), 777, k, bi, bd)
+        assert p.num_targets == m
+        b_i = torch.empty_like(a_i); b_d = torch.empty_like(a_d)
+        p.query_resident_dev(k, b_i, b_d)
+        torch.cuda.synchronize()
+        assert torch.equal(a_i, b_i) and torch.equal(a_d, b_d)
+        # the bounded query returns exactly the neighbours within the bound
+        wi, wd = oracle.knn_bruteforce(oracle.synth_xyz(seed, 0, n), other, k)
+        out = wd > 1e-3
+        wi[out] = 0xFFFFFFFF; wd[out] = np.inf
+        assert np.array_equal(bi.cpu().numpy().view(np.uint32), wi) and np.array_equal(bd.cpu().numpy(), wd)
+
+
 # ---- edge cases the domain has ---------------------------------------------------------------------------
 def test_duplicates_and_exact_ties(pt, oracle):
     rng = np.random.default_rng(1)
