@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpt_hip.so")
+LIB_PATH = os.environ.get("PT_HIP_LIB") or os.path.join(_HERE, "libpt_hip.so")   # PT_HIP_LIB: profiling/ablation builds only
 
 NOIDX = 0xFFFFFFFF
 MAX_K = 32

@@ -557,6 +557,9 @@ __global__ __launch_bounds__(TWG, 1) void knn_tile_kernel(GridParams gp, const R
     }
   }
   __syncthreads();                                  // gstart is dead from here on: the queue takes its place
+#if defined(PT_ABLATE) && PT_ABLATE == 1
+  return;                                           // timing-only build: staging cost alone (results are garbage)
+#endif
 
   // ---- C: four lanes per target, 192 targets per round ----------------------------------------------------------------
   const double h2 = gp.h * gp.h;
@@ -622,6 +625,9 @@ __global__ __launch_bounds__(TWG, 1) void knn_tile_kernel(GridParams gp, const R
     for (int j = 1; j < K; ++j) kv = (j == k - 1) ? l32[j] : kv;
     const float thr = kth_bound32(kv);
     const double lim = (double)thr;
+#if defined(PT_ABLATE) && PT_ABLATE == 2
+    if (thr >= 0.f) continue;                       // timing-only build: staging + pass 1 (results are garbage)
+#endif
 
     // ---- pass 2: re-scan under the bound, queue what is within it ----
     auto gap = [&](int a, int lo, int hi) -> double {

@@ -50,6 +50,24 @@ def kernel_alg_bytes(name, n, m, k, s=12):
     }[name]
 
 
+PMC_KERNEL = {"bbox_reduce": "bbox_kernel", "pass1_histogram": "hist_chunk_kernel", "pass1_scatter": "scatter_chunk_kernel",
+              "pass2_histogram_scan": "hist_kernel", "pass2_scatter": "scatter_kernel", "finalize_cellsort": "finalize_kernel",
+              "knn_query": "knn_tile_kernel"}
+
+
+def pmc_traffic(kernel, workload, world):
+    """HBM bytes of one launch of `kernel` from the committed rocprofv3 PMC passes of the same workload
+    (profiles/r01_v4_c4_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE doubled as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950).  None when no matching profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_v4_c4_pmc_traffic.json")
+    if workload != "C4" or world != 1 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        prof = json.load(f)
+    rec = prof["kernels"].get(PMC_KERNEL.get(kernel, ""))
+    return rec["hbm_bytes"] if rec else None
+
+
 def cpu_baseline(n_total, m_total, k, seed):
     """The oracle's kd-tree restatement of the reference's CPU search (kind "port"), timed on this host's cores on a
     bounded sample with the workload's N/M ratio.  Reported beside the GPU number -- never the target."""
@@ -197,7 +215,7 @@ def main():
                        "step": "grid build + target binning + k-NN + slab exchange/merge + mean blend, inputs resident in HBM",
                        "parallelism": "slab%d" % world if world > 1 else "single", "backend": args.backend if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(KERNEL_NAMES[dom], args.workload, world),
                          "alg_bytes_per_launch": alg, "avg_launch_ms": kavg[dom]},
             "job_roofline": {"alg_bytes_per_step": b_alg_job, "achieved": b_alg_job / (ms_per_step * 1e-3) / 1e9 / world, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s per GPU", "frac": b_alg_job / (ms_per_step * 1e-3) / 1e9 / world / HBM_PEAK_GBS},

@@ -93,7 +93,7 @@ void pt_ctx_destroy(pt_ctx*);
  * kernels queue behind whatever produced the device buffers handed in.  NULL = HIP's default stream;
  * pt_set_param(ctx, "own_stream", 1) returns to the context's own (non-blocking) stream. */
 int  pt_set_stream(pt_ctx*, void* hip_stream);
-/* Tunables: "rho" (target points per grid cell, default 8), "sync" (1 = every call blocks until
+/* Tunables: "rho" (target points per grid cell, default 6), "sync" (1 = every call blocks until
  * the GPU is done, default 1; 0 = _dev calls only enqueue), "tile" (1 = tile kernel + group kernel for its
  * leftovers, default; 0 = group kernel only). */
 int  pt_set_param(pt_ctx*, const char* name, double value);
