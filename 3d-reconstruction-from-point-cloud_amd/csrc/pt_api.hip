@@ -294,13 +294,30 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
   return PT_OK;
 }
 
+// planar xyz of any supported type -> device buffer `dst` in the type the kernels run on (fp16 is widened to fp32, exactly)
+int upload_xyz(pt_ctx* c, DevBuf& dst, const void* xyz, int& xyz_type, uint64_t n, int on_device) {
+  if (xyz_type != PT_F32 && xyz_type != PT_F64 && xyz_type != PT_F16) return fail(c, PT_ERR_ARG, "unknown xyz_type %d", xyz_type);
+  if (n && !xyz) return fail(c, PT_ERR_ARG, "xyz is null");
+  if (xyz_type == PT_F16) {
+    RES(c, dst, std::max<uint64_t>(n, 1) * 3 * sizeof(float));
+    const void* src = xyz;
+    if (!on_device) {
+      RES(c, c->misc, std::max<uint64_t>(n, 1) * 3 * 2);
+      { int r = copy_in(c, c->misc.p, xyz, n * 3 * 2, 0); if (r) return r; }
+      src = c->misc.p;
+    }
+    pt_launch_half_to_float(src, (float*)dst.p, n * 3, c->stream);
+    xyz_type = PT_F32;
+    return PT_OK;
+  }
+  RES(c, dst, std::max<uint64_t>(n, 1) * 3 * tsize(xyz_type));
+  return copy_in(c, dst.p, xyz, n * 3 * tsize(xyz_type), on_device);
+}
+
 // copy caller targets into the transient buffer (resident targets are not touched)
-int load_transient(pt_ctx* c, const void* xyz, int xyz_type, uint64_t m, int on_device) {
-  if (xyz_type != PT_F32 && xyz_type != PT_F64) return fail(c, PT_ERR_UNSUPPORTED, "xyz_type %d not supported yet (f32 and f64 are)", xyz_type);
-  if (m && !xyz) return fail(c, PT_ERR_ARG, "target xyz is null");
+int load_transient(pt_ctx* c, const void* xyz, int& xyz_type, uint64_t m, int on_device) {
   { int r = check_n(c, m, "m"); if (r) return r; }
-  RES(c, c->x_xyz, std::max<uint64_t>(m, 1) * 3 * tsize(xyz_type));
-  return copy_in(c, c->x_xyz.p, xyz, m * 3 * tsize(xyz_type), on_device);
+  return upload_xyz(c, c->x_xyz, xyz, xyz_type, m, on_device);
 }
 
 }  // namespace
@@ -400,12 +417,9 @@ int pt_build_aos(pt_ctx* c, const pt_point* cloud, uint64_t n) {
 
 int pt_build_soa_indexed(pt_ctx* c, const void* xyz, int xyz_type, const uint32_t* gidx, uint64_t n, int on_device) {
   if (!c) return PT_ERR_ARG;
-  if (xyz_type != PT_F32 && xyz_type != PT_F64) return fail(c, PT_ERR_UNSUPPORTED, "xyz_type %d not supported yet (f32 and f64 are)", xyz_type);
-  if (n && !xyz) return fail(c, PT_ERR_ARG, "xyz is null");
   { int r = check_n(c, n, "n"); if (r) return r; }
   HIPCHK(c, hipSetDevice(c->device));
-  RES(c, c->in_xyz, std::max<uint64_t>(n, 1) * 3 * tsize(xyz_type));
-  { int r = copy_in(c, c->in_xyz.p, xyz, n * 3 * tsize(xyz_type), on_device); if (r) return r; }
+  { int r = upload_xyz(c, c->in_xyz, xyz, xyz_type, n, on_device); if (r) return r; }
   if (gidx) {
     RES(c, c->in_gidx, std::max<uint64_t>(n, 1) * sizeof(uint32_t));
     { int r = copy_in(c, c->in_gidx.p, gidx, n * sizeof(uint32_t), on_device); if (r) return r; }
@@ -444,7 +458,9 @@ int pt_build_soa(pt_ctx* c, const void* xyz, int xyz_type, const uint8_t* rgb, c
 int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz_type, int slab_axis, double slab_lo, double slab_hi) {
   if (!c) return PT_ERR_ARG;
   if (dist != PT_DIST_UNIFORM) return fail(c, PT_ERR_UNSUPPORTED, "only the uniform generator is implemented");
-  if (xyz_type != PT_F32 && xyz_type != PT_F64) return fail(c, PT_ERR_UNSUPPORTED, "xyz_type %d not supported yet (f32 and f64 are)", xyz_type);
+  if (xyz_type != PT_F32 && xyz_type != PT_F64 && xyz_type != PT_F16) return fail(c, PT_ERR_ARG, "unknown xyz_type %d", xyz_type);
+  const int f16 = xyz_type == PT_F16;      // fp16 values, held widened as fp32 on the device
+  if (f16) xyz_type = PT_F32;
   if (slab_axis > 2) return fail(c, PT_ERR_ARG, "slab_axis must be < 3");
   { int r = check_n(c, n_total, "n_total"); if (r) return r; }
   HIPCHK(c, hipSetDevice(c->device));
@@ -452,7 +468,7 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
   const bool slab = slab_axis >= 0;
   if (slab) {   // counting pass
     HIPCHK(c, hipMemsetAsync(c->counter.p, 0, 4, c->stream));
-    pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, nullptr, nullptr, nullptr, nullptr, (uint32_t*)c->counter.p, 0, c->stream);
+    pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, nullptr, nullptr, nullptr, nullptr, (uint32_t*)c->counter.p, 0, f16, c->stream);
     HIPCHK(c, hipMemcpyAsync(c->h_counter, c->counter.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     n = *c->h_counter;
@@ -461,8 +477,8 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
   }
   RES(c, c->in_xyz, std::max<uint64_t>(n, 1) * 3 * tsize(xyz_type));
   uint32_t* g = slab ? (uint32_t*)c->in_gidx.p : nullptr;
-  if (xyz_type == PT_F32) { float* x = (float*)c->in_xyz.p; pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, c->stream); }
-  else { double* x = (double*)c->in_xyz.p; pt_launch_synth_xyz<double>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, c->stream); }
+  if (xyz_type == PT_F32) { float* x = (float*)c->in_xyz.p; pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, c->stream); }
+  else { double* x = (double*)c->in_xyz.p; pt_launch_synth_xyz<double>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, c->stream); }
   RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
   pt_launch_synth_attr(seed, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
   c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false;
@@ -478,7 +494,9 @@ int pt_rebuild(pt_ctx* c) {
 int pt_targets_synth(pt_ctx* c, uint64_t m_total, uint64_t seed, int dist, int xyz_type, int slab_axis, double slab_lo, double slab_hi) {
   if (!c) return PT_ERR_ARG;
   if (dist != PT_DIST_UNIFORM) return fail(c, PT_ERR_UNSUPPORTED, "only the uniform generator is implemented");
-  if (xyz_type != PT_F32 && xyz_type != PT_F64) return fail(c, PT_ERR_UNSUPPORTED, "xyz_type %d not supported yet (f32 and f64 are)", xyz_type);
+  if (xyz_type != PT_F32 && xyz_type != PT_F64 && xyz_type != PT_F16) return fail(c, PT_ERR_ARG, "unknown xyz_type %d", xyz_type);
+  const int f16 = xyz_type == PT_F16;
+  if (f16) xyz_type = PT_F32;
   if (slab_axis > 2) return fail(c, PT_ERR_ARG, "slab_axis must be < 3");
   { int r = check_n(c, m_total, "m_total"); if (r) return r; }
   HIPCHK(c, hipSetDevice(c->device));
@@ -486,7 +504,7 @@ int pt_targets_synth(pt_ctx* c, uint64_t m_total, uint64_t seed, int dist, int x
   const bool slab = slab_axis >= 0;
   if (slab) {
     HIPCHK(c, hipMemsetAsync(c->counter.p, 0, 4, c->stream));
-    pt_launch_synth_xyz<float>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, nullptr, nullptr, nullptr, nullptr, (uint32_t*)c->counter.p, 0, c->stream);
+    pt_launch_synth_xyz<float>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, nullptr, nullptr, nullptr, nullptr, (uint32_t*)c->counter.p, 0, f16, c->stream);
     HIPCHK(c, hipMemcpyAsync(c->h_counter, c->counter.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     m = *c->h_counter;
@@ -495,8 +513,8 @@ int pt_targets_synth(pt_ctx* c, uint64_t m_total, uint64_t seed, int dist, int x
   RES(c, c->t_gidx, std::max<uint64_t>(m, 1) * sizeof(uint32_t));
   RES(c, c->t_xyz, std::max<uint64_t>(m, 1) * 3 * tsize(xyz_type));
   uint32_t* g = (uint32_t*)c->t_gidx.p;
-  if (xyz_type == PT_F32) { float* x = (float*)c->t_xyz.p; pt_launch_synth_xyz<float>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, x, x + m, x + 2 * m, g, (uint32_t*)c->counter.p, (uint32_t)m, c->stream); }
-  else { double* x = (double*)c->t_xyz.p; pt_launch_synth_xyz<double>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, x, x + m, x + 2 * m, g, (uint32_t*)c->counter.p, (uint32_t)m, c->stream); }
+  if (xyz_type == PT_F32) { float* x = (float*)c->t_xyz.p; pt_launch_synth_xyz<float>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, x, x + m, x + 2 * m, g, (uint32_t*)c->counter.p, (uint32_t)m, f16, c->stream); }
+  else { double* x = (double*)c->t_xyz.p; pt_launch_synth_xyz<double>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, x, x + m, x + 2 * m, g, (uint32_t*)c->counter.p, (uint32_t)m, f16, c->stream); }
   c->tgt_type = xyz_type; c->m = m; c->t_has_gidx = true;
   return finish(c);
 }

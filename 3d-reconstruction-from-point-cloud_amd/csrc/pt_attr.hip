@@ -8,6 +8,8 @@
 //   * PCA normals from the neighbours (BASELINE config 3; no reference counterpart).
 #include "pt_internal.h"
 
+#include <hip/hip_fp16.h>
+
 namespace {
 
 constexpr int WG = 256;
@@ -24,12 +26,15 @@ __device__ inline float u24(uint64_t h) { return (float)(uint32_t)(h >> 40) * (1
 template <class T>
 __global__ __launch_bounds__(WG) void synth_xyz_kernel(uint64_t key, uint32_t n_total, int axis, double lo, double hi, T* __restrict__ x,
                                                        T* __restrict__ y, T* __restrict__ z, uint32_t* __restrict__ gidx, uint32_t* counter,
-                                                       uint32_t capacity) {
+                                                       uint32_t capacity, int round_f16) {
   const uint32_t i = blockIdx.x * WG + threadIdx.x;
   if (i >= n_total) return;
-  const float px = u24(splitmix64(key + 4ull * i + 0));
-  const float py = u24(splitmix64(key + 4ull * i + 1));
-  const float pz = u24(splitmix64(key + 4ull * i + 2));
+  float px = u24(splitmix64(key + 4ull * i + 0));
+  float py = u24(splitmix64(key + 4ull * i + 1));
+  float pz = u24(splitmix64(key + 4ull * i + 2));
+  if (round_f16) {   // BASELINE config 5: xyz = half_rn(fp32 value), widened back exactly
+    px = __half2float(__float2half_rn(px)); py = __half2float(__float2half_rn(py)); pz = __half2float(__float2half_rn(pz));
+  }
   uint32_t pos = i;
   if (axis >= 0) {
     const double c = (double)(axis == 0 ? px : (axis == 1 ? py : pz));
@@ -121,7 +126,7 @@ __device__ inline void jacobi3(double (&a)[3][3], double (&v)[3][3]) {
     for (int j = 0; j < 3; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 64; ++sweep) {
     const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
-    if (off < 1e-300) break;
+    if (off <= 1e-20 * (fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]))) break;   // converged far below fp64 resolution
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -146,29 +151,31 @@ __global__ __launch_bounds__(WG) void pca_kernel(const uint32_t* __restrict__ id
                                                  float* __restrict__ nrm_out) {
   const uint32_t t = blockIdx.x * WG + threadIdx.x;
   if (t >= m) return;
-  double mu[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+  // one gather pass: moments about the first neighbour (a shift keeps Sum(dd^T) - Sum(d)Sum(d)^T/n free of cancellation)
+  double mn[3] = {0, 0, 0}, sd[3] = {0, 0, 0}, o[3] = {0, 0, 0};
+  double cv[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   int ke = 0;
   for (int j = 0; j < k; ++j) {
     const uint32_t id = idx[(size_t)t * k + j];
     if (id == PT_NOIDX_U || id >= n) continue;
-    mu[0] += (double)x[id]; mu[1] += (double)y[id]; mu[2] += (double)z[id];
-    ++ke;
-    if (attr) { const Attr a = attr[id]; mn[0] += (double)a.nx; mn[1] += (double)a.ny; mn[2] += (double)a.nz; }
-  }
-  float* o = nrm_out + 3 * (size_t)t;
-  if (ke < 3) { o[0] = 0.f; o[1] = 0.f; o[2] = 1.f; return; }
+    const double p[3] = {(double)x[id], (double)y[id], (double)z[id]};
+    if (ke == 0) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+    const double d[3] = {p[0] - o[0], p[1] - o[1], p[2] - o[2]};
 #pragma unroll
-  for (int a = 0; a < 3; ++a) mu[a] /= (double)ke;
-  double cv[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  for (int j = 0; j < k; ++j) {
-    const uint32_t id = idx[(size_t)t * k + j];
-    if (id == PT_NOIDX_U || id >= n) continue;
-    const double d[3] = {(double)x[id] - mu[0], (double)y[id] - mu[1], (double)z[id] - mu[2]};
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 3; ++a) {
+      sd[a] += d[a];
 #pragma unroll
       for (int b = 0; b < 3; ++b) cv[a][b] += d[a] * d[b];
+    }
+    ++ke;
+    if (attr) { const Attr at = attr[id]; mn[0] += (double)at.nx; mn[1] += (double)at.ny; mn[2] += (double)at.nz; }
   }
+  float* o3 = nrm_out + 3 * (size_t)t;
+  if (ke < 3) { o3[0] = 0.f; o3[1] = 0.f; o3[2] = 1.f; return; }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) cv[a][b] -= sd[a] * sd[b] / (double)ke;
   double v[3][3];
   jacobi3(cv, v);
   const double e0 = cv[0][0], e1 = cv[1][1], e2 = cv[2][2];
@@ -179,7 +186,13 @@ __global__ __launch_bounds__(WG) void pca_kernel(const uint32_t* __restrict__ id
   const double len = sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
   const double ref = attr ? (nn[0] * mn[0] + nn[1] * mn[1] + nn[2] * mn[2]) : nn[2];
   const double sgn = (ref < 0 ? -1.0 : 1.0) / len;
-  o[0] = (float)(nn[0] * sgn); o[1] = (float)(nn[1] * sgn); o[2] = (float)(nn[2] * sgn);
+  o3[0] = (float)(nn[0] * sgn); o3[1] = (float)(nn[1] * sgn); o3[2] = (float)(nn[2] * sgn);
+}
+
+// fp16 planar xyz -> fp32 planar xyz (exact widening): fp16 clouds run through the fp32 path unchanged
+__global__ __launch_bounds__(WG) void half_to_float_kernel(const __half* __restrict__ in, float* __restrict__ out, uint64_t count) {
+  const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+  if (i < count) out[i] = __half2float(in[i]);
 }
 
 __global__ __launch_bounds__(WG) void iota_kernel(uint32_t* p, uint32_t n) {
@@ -193,15 +206,15 @@ inline dim3 grid_for(uint32_t n) { return dim3((n + WG - 1) / WG); }
 
 template <class T>
 void pt_launch_synth_xyz(uint64_t seed, uint64_t stream, uint32_t n_total, int axis, double lo, double hi, T* x, T* y, T* z, uint32_t* gidx,
-                         uint32_t* counter, uint32_t capacity, hipStream_t s) {
+                         uint32_t* counter, uint32_t capacity, int round_f16, hipStream_t s) {
   if (!n_total) return;
   hipLaunchKernelGGL(synth_xyz_kernel<T>, grid_for(n_total), dim3(WG), 0, s, stream_key(seed, stream), n_total, axis, lo, hi, x, y, z, gidx,
-                     counter, capacity);
+                     counter, capacity, round_f16);
 }
 template void pt_launch_synth_xyz<float>(uint64_t, uint64_t, uint32_t, int, double, double, float*, float*, float*, uint32_t*, uint32_t*, uint32_t,
-                                         hipStream_t);
+                                         int, hipStream_t);
 template void pt_launch_synth_xyz<double>(uint64_t, uint64_t, uint32_t, int, double, double, double*, double*, double*, uint32_t*, uint32_t*,
-                                          uint32_t, hipStream_t);
+                                          uint32_t, int, hipStream_t);
 
 void pt_launch_synth_attr(uint64_t seed, uint32_t n_total, Attr* attr, hipStream_t s) {
   if (!n_total) return;
@@ -233,4 +246,8 @@ template void pt_launch_pca<double>(const uint32_t*, uint32_t, int, const double
 void pt_launch_iota(uint32_t* p, uint32_t n, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(WG), 0, s, p, n);
+}
+void pt_launch_half_to_float(const void* in_half, float* out, uint64_t count, hipStream_t s) {
+  if (!count) return;
+  hipLaunchKernelGGL(half_to_float_kernel, dim3((uint32_t)((count + WG - 1) / WG)), dim3(WG), 0, s, (const __half*)in_half, out, count);
 }

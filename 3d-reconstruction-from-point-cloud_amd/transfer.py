@@ -21,7 +21,7 @@ K_REFERENCE = 20   # `const unsigned int K = 20`, reference src/pointsTransfer.c
 
 
 def _np_type(xyz_type):
-    return np.float64 if xyz_type == capi.F64 else np.float32
+    return {capi.F64: np.float64, capi.F16: np.float16}.get(xyz_type, np.float32)
 
 
 def _planar(xyz, xyz_type=None):
@@ -29,7 +29,7 @@ def _planar(xyz, xyz_type=None):
     if a.ndim != 2 or a.shape[0] != 3:
         raise ValueError("xyz must be planar with shape (3, n)")
     if xyz_type is None:
-        xyz_type = capi.F64 if a.dtype == np.float64 else capi.F32
+        xyz_type = capi.F64 if a.dtype == np.float64 else (capi.F16 if a.dtype == np.float16 else capi.F32)
     return np.ascontiguousarray(a, dtype=_np_type(xyz_type)), xyz_type
 
 

@@ -158,6 +158,8 @@ def main():
     xyz = torch.empty((3, m_loc), dtype=torch.float32, device=dev)
     pt.resident_target_xyz_dev(xyz)
     engine = sharding.GpuSlabEngine(pt, pkg.F32, dev)
+    with_pca = args.workload == "C3" and world == 1          # PCA needs the whole cloud resident (no slabs)
+    pnrm = torch.empty((m_loc, 3), dtype=torch.float32, device=dev) if with_pca else None
 
     kms = [0.0] * 8
     phase = {"build": 0.0, "target_sort": 0.0, "knn": 0.0, "blend": 0.0}
@@ -169,7 +171,11 @@ def main():
         st = pt.stats() if record else None       # HIP-event times of the build + home search, on the stream they ran on
         xs = sharding.exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds)
         pt.blend_dev(idx, d2, m_loc, k, pkg.BLEND_MEAN, rgb, nrm)
+        if with_pca:
+            pt.pca_normals_dev(idx, m_loc, k, pnrm)     # BASELINE config 3: PCA normal estimation from the neighbours
         if record:
+            if with_pca:
+                phase["pca"] = phase.get("pca", 0.0) + pt.stats()["ms_pca"]
             for i in range(8):
                 kms[i] += st["ms_kernel"][i]
             phase["build"] += st["ms_build"]; phase["target_sort"] += st["ms_sort_targets"]
@@ -212,7 +218,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d-point source / %d targets / k=%d, uniform fp32 xyz in the unit cube, generator seed 0x%X"
                                    % (args.workload, n_total, m_total, k, seed),
-                       "step": "grid build + target binning + k-NN + slab exchange/merge + mean blend, inputs resident in HBM",
+                       "step": "grid build + target binning + k-NN + slab exchange/merge + mean blend%s, inputs resident in HBM"
+                               % (" + PCA normals" if with_pca else ""),
                        "parallelism": "slab%d" % world if world > 1 else "single", "backend": args.backend if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(KERNEL_NAMES[dom], args.workload, world),

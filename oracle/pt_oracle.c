@@ -445,7 +445,7 @@ static void jacobi3(double a[3][3], double v[3][3], double ev[3]) {
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) v[i][j] = (i == j);
   for (int sweep = 0; sweep < 64; ++sweep) {
     const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
-    if (off < 1e-300) break;
+    if (off <= 1e-20 * (fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]))) break;   /* converged far below fp64 resolution */
     for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
       if (fabs(a[p][q]) < 1e-300) continue;
       const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);

@@ -200,6 +200,69 @@ def test_aos_point_records_double_path(pkg, pt, oracle):
     _check_exact(pt.query(verts["ver"].T.copy(), k, xyz_type=pkg.F64), want, "planar f64")
 
 
+def test_fp16_coordinates(pkg, pt, oracle):
+    """BASELINE config 5's coordinate type: fp16 xyz, ranked exactly like the oracle on the widened values."""
+    import torch
+    rng = np.random.default_rng(16)
+    src = rng.random((3, 60000)).astype(np.float16)          # heavy duplication: only ~1000 distinct values per axis
+    tgt = rng.random((3, 3000)).astype(np.float16)
+    pt.build(src)
+    got = pt.query(tgt, 8)
+    _check_exact(got, oracle.knn_bruteforce(src.astype(np.float64), tgt.astype(np.float64), 8), "fp16 host arrays")
+    with pkg.PointsTransfer(device=0) as p:                    # the on-device generator rounds to fp16 the same way
+        n, m, k, seed = 80000, 5000, 8, 0xC5
+        p.build_synth(n, seed, xyz_type=pkg.F16)
+        p.targets_synth(m, seed, xyz_type=pkg.F16)
+        xyz = torch.empty((3, m), dtype=torch.float32, device="cuda")
+        p.resident_target_xyz_dev(xyz)
+        t16 = oracle.synth_xyz(seed, 1, m).astype(np.float16)
+        assert np.array_equal(xyz.cpu().numpy(), t16.astype(np.float32))
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        p.query_resident_dev(k, idx, d2)
+        torch.cuda.synchronize()
+        s16 = oracle.synth_xyz(seed, 0, n).astype(np.float16)
+        _check_exact((idx.cpu().numpy().view(np.uint32), d2.cpu().numpy()), oracle.KdTree(s16.astype(np.float64)).query(t16.astype(np.float64), k), "fp16 generator")
+
+
+def test_cli_end_to_end(tmp_path, pkg, oracle):
+    """The C++ pointsTransfer CLI (reference argv + stdout lines) over the C ABI, on ASCII PLY files of the reference's
+    grammar (cloud: x y z nx ny nz r g b; mesh: x y z nx ny nz u v r g b + faces), K = 20 as the reference."""
+    import os, subprocess
+    rng = np.random.default_rng(12)
+    n, m, k = 5000, 300, 20
+    cloud = np.round(rng.random((n, 3)) * [4, 2, 1], 6)                    # decimal text -> doubles that are not fp32 values
+    cnrm = np.round(rng.standard_normal((n, 3)), 6); crgb = rng.integers(0, 256, (n, 3))
+    verts = np.round(rng.random((m, 3)) * [4, 2, 1], 6)
+    pc, mesh = tmp_path / "cloud.ply", tmp_path / "mesh.ply"
+    with open(pc, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\n"
+                "property float ny\nproperty float nz\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % n)
+        for p_, q_, c_ in zip(cloud, cnrm, crgb):
+            f.write("%.6f %.6f %.6f %.6f %.6f %.6f %d %d %d\n" % (*p_, *q_, *c_))
+    with open(mesh, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\n"
+                "property float ny\nproperty float nz\nproperty float s\nproperty float t\nproperty uchar red\nproperty uchar green\n"
+                "property uchar blue\nelement face 2\nproperty list uchar int vertex_indices\nend_header\n" % m)
+        for v in verts:
+            f.write("%.6f %.6f %.6f 0 0 1 0.5 0.5 1 2 3\n" % tuple(v))
+        f.write("3 0 1 2\n3 2 1 3\n")
+    exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "pointsTransfer")
+    nb = tmp_path / "nn.bin"
+    r = subprocess.run([exe, str(pc), str(mesh), "--neighbors", str(nb), "--out", str(tmp_path / "out.ply")], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    lines = [l.split(":")[0] for l in r.stdout.strip().splitlines()]
+    assert lines == ["PC Point count", "Read point set in", "Built Kd tree in", "Mesh vertex count", "Mesh face count", "Read mesh faces",
+                     "Neighbor search total time", "Draw triangles total time", "Output time", "Total real time", "VIRT", "RES"]   # reference order
+    assert "PC Point count: %d" % n in r.stdout and "Mesh vertex count: %d" % m in r.stdout and "Mesh face count: 2" in r.stdout
+    got = np.fromfile(nb, dtype=np.uint32).reshape(m, k)
+    want, wd = oracle.knn_bruteforce(cloud.T, verts.T, k)                 # the doubles atof/strtod produce from the text
+    assert np.array_equal(got, want)
+    out = [l.split() for l in open(tmp_path / "out.ply").read().split("end_header\n")[1].strip().splitlines()]
+    rc, rn = oracle.blend(want, wd, crgb.astype(np.uint8), cnrm.astype(np.float32), 0)
+    col = np.array([[int(v) for v in row[8:11]] for row in out[:m]])
+    assert np.abs(col - np.floor(rc)).max() <= 1                           # float -> uchar truncation, as the reference's rasteriser
+
+
 # ---- blend and PCA -------------------------------------------------------------------------------------------
 def test_blend_modes_match_golden(pt, oracle, golden, golden_cases):
     src, tgt = golden_cases["c1"]
