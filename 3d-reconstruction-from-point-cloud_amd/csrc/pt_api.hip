@@ -35,7 +35,8 @@ struct pt_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t sev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per-kernel marks of the source sort
   std::string err;
-  double rho = 6.0;            // points per cell: measured optimum of the tile kernel at C4 (8: 39.8 ms, 6: 34.0 ms, 4: 38.0 ms)
+  double rho = 4.0;            // points per cell: 10^3-cell regions of ~4000 records let TWO tile workgroups share a CU
+                               // (k-NN at C4: rho 8 -> 39.8 ms, 6 -> 32.4 ms, 4 with the small geometry -> 23.2 ms)
   int sync = 1;
   int tile = 1;                // 1: tile kernel + group kernel for leftovers (fp32, unbounded); 0: group kernel only
   size_t dev_bytes = 0;
@@ -255,11 +256,14 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     const float* x = (const float*)txyz;
     pt_launch_grid_sort<float, RecF>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecF*)c->trec.p, (RecF*)c->trec_tmp.p, nullptr, c->ttb, c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    if (c->tile && !bound2_dev && m) {
+    if (c->tile && !bound2_dev && m && k <= 24) {     // beyond k = 24 a region that holds ring 1 no longer fits LDS
+      // regions (10^3 cells) that fit 4480 records with headroom run the two-workgroups-per-CU geometry
+      const double cells = (double)c->gp.dim[0] * c->gp.dim[1] * c->gp.dim[2];
+      const int tile_small = c->tile == 2 || (c->tile == 1 && (double)c->n / cells * 1000.0 * 1.05 <= (k <= 8 ? 4480.0 : (k <= 16 ? 4224.0 : 3968.0)));
       uint32_t* todo_n = (uint32_t*)c->counter.p + 4;
       HIPCHK(c, hipMemsetAsync(todo_n, 0, 4, c->stream));
       pt_launch_knn_tile(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecF*)c->trec.p, c->ttb.block_start, k, idx_dev, d2_dev,
-                         (uint32_t*)c->todo.p, todo_n, c->stream);
+                         (uint32_t*)c->todo.p, todo_n, tile_small, c->stream);
       pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecF*)c->trec.p, m, k, nullptr, idx_dev, d2_dev,
                           (const uint32_t*)c->todo.p, todo_n, c->stream);
       HIPCHK(c, hipMemcpyAsync(c->h_counter + 4, todo_n, 4, hipMemcpyDeviceToHost, c->stream));
@@ -289,7 +293,7 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     c->st.ms_query = b;
     c->st.ms_kernel[6] = a;
     c->st.ms_kernel[7] = b;
-    c->st.n_leftover = (c->tile && !bound2_dev && m && ttype == PT_F32) ? c->h_counter[4] : 0;
+    c->st.n_leftover = (c->tile && !bound2_dev && m && k <= 24 && ttype == PT_F32) ? c->h_counter[4] : 0;
   }
   return PT_OK;
 }
@@ -375,8 +379,16 @@ int pt_set_stream(pt_ctx* c, void* hip_stream) {
 int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!c || !name) return PT_ERR_ARG;
   if (!strcmp(name, "rho")) { if (!(value >= 0.25 && value <= 4096)) return fail(c, PT_ERR_ARG, "rho out of range"); c->rho = value; return PT_OK; }
+  if (!strcmp(name, "k_hint")) {
+    // cell density for the k the caller is going to ask for: ring 1 (3x3x3 cells) must usually contain the k nearest
+    // (expected k-th distance ~0.8 cell sides), and a 10^3-cell region must fit the tile kernel's LDS budget
+    const int k = (int)value;
+    if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k_hint out of range");
+    c->rho = k <= 8 ? 4.0 : (k <= 16 ? 6.0 : (k <= 24 ? 8.0 : 12.0));
+    return PT_OK;
+  }
   if (!strcmp(name, "sync")) { c->sync = value != 0; return PT_OK; }
-  if (!strcmp(name, "tile")) { c->tile = value != 0; return PT_OK; }
+  if (!strcmp(name, "tile")) { c->tile = (int)value; return PT_OK; }   // 0 group kernel only, 1 auto, 2 small tiles, 3 large tiles
   if (!strcmp(name, "own_stream")) { if (value != 0) c->stream = c->own_stream; return PT_OK; }
   return fail(c, PT_ERR_ARG, "unknown parameter '%s'", name);
 }

@@ -48,7 +48,7 @@ void pt_launch_knn(const GridParams& gp, const Rec* src, const uint32_t* cell_st
                    const double* bound2, uint32_t* out_idx, double* out_d2, const uint32_t* list, const uint32_t* list_n, hipStream_t s);
 // one-thread-per-target tile kernel (fp32 records); leftovers go to todo[*todo_n] and are finished by pt_launch_knn(list=todo)
 void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* cell_start, const RecF* tgt, const uint32_t* tblock_start,
-                        int k, uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, hipStream_t s);
+                        int k, uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int small, hipStream_t s);
 void pt_launch_merge(const uint32_t* idx_lists, const double* d2_lists, int g, uint32_t m, int k, uint32_t* idx_out,
                      double* d2_out, hipStream_t s);
 template <class T>

@@ -380,12 +380,11 @@ __global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __res
 // Targets that ring 1 cannot settle (k-th neighbour farther than the region guarantees, more near-ties than the queue
 // holds, region larger than the LDS budget) are appended to `todo` and finished by the group kernel.  fp32 records
 // only (the fp32 pre-filter needs exact fp32 inputs).
-constexpr int TWG = 768;             // 12 waves = 192 quads per workgroup (one workgroup per CU: LDS-bound)
 constexpr int TILE_R = 10, TILE_CELLS = TILE_R * TILE_R * TILE_R;
-constexpr int TILE_CAP = 8448;       // records staged per tile (132 KB); a uniform rho = 8 region holds 8000 +- 90
+// Two geometries: LARGE = 768 threads, 8448 staged records (132 KB, one workgroup per CU) for rho ~ 6-8;
+//                 SMALL = 512 threads, 4480 staged records ( 70 KB, two workgroups per CU: one stages while the other ranks).
 // queue entries per quad: room for the k survivors plus near-ties (LDS-limited at K = 32)
 template <int K> struct TileQ { static constexpr int CAP = K == 8 ? 16 : (K == 16 ? 32 : 48); };
-constexpr int TILE_QUADS = TWG / 4;
 
 __device__ inline float dist2_f32(float qx, float qy, float qz, const RecF& r) {
   const float dx = qx - r.x, dy = qy - r.y, dz = qz - r.z;
@@ -428,12 +427,13 @@ __device__ inline void quad_merge_sorted(float (&l)[K]) {
   for (int j = 0; j < K; ++j) l[j] = c[j];
 }
 
-template <int K>
-__global__ __launch_bounds__(TWG, 1) void knn_tile_kernel(GridParams gp, const RecF* __restrict__ src, const uint32_t* __restrict__ cs,
+template <int K, int TILE_CAP, int TWG>
+__global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(GridParams gp, const RecF* __restrict__ src, const uint32_t* __restrict__ cs,
                                                         const RecF* __restrict__ tgt, const uint32_t* __restrict__ tblock_start, int k,
                                                         uint32_t* __restrict__ out_idx, double* __restrict__ out_d2,
                                                         uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_n) {
   constexpr int NW = TWG / 64;
+  constexpr int TILE_QUADS = TWG / 4;
   constexpr int TILE_QCAP = TileQ<K>::CAP;
   __shared__ __attribute__((aligned(16))) RecF lrec[TILE_CAP];
   __shared__ uint32_t lstart[TILE_CELLS + 8];
@@ -504,22 +504,32 @@ __global__ __launch_bounds__(TWG, 1) void knn_tile_kernel(GridParams gp, const R
     uint4* l4 = reinterpret_cast<uint4*>(lrec);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int NROWS = TILE_R * TILE_R;
-    constexpr int RB = (NROWS + NW - 1) / NW;                       // 9 rows per wave
-    uint4 t0[RB], t1[RB];
-    uint32_t la[RB], len[RB];
+    constexpr int RPW = (NROWS + NW - 1) / NW;                      // rows per wave (9 or 13)
+    constexpr int RB = TILE_CAP > 5000 ? RPW : (RPW + 1) / 2;       // rows per batch: bounded by the VGPR budget of the geometry
     bool long_rows = false;
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const int rr = w + i * NW;
-      const int row = rr < NROWS ? rr : NROWS - 1;
-      const int c1 = row * TILE_R + 1;
-      la[i] = lstart[c1];
-      len[i] = rr < NROWS ? lstart[c1 + 8] - la[i] : 0u;
-      const uint32_t ga = gstart[c1];
-      t0[i] = make_uint4(0, 0, 0, 0); t1[i] = make_uint4(0, 0, 0, 0);
-      if ((uint32_t)lane < len[i]) t0[i] = src4[ga + lane];
-      if ((uint32_t)lane + 64u < len[i]) t1[i] = src4[ga + lane + 64u];
-      long_rows |= len[i] > 128u;
+    for (int b0 = 0; b0 < RPW; b0 += RB) {
+      uint4 t0[RB], t1[RB];
+      uint32_t la[RB], len[RB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int rr = w + (b0 + i) * NW;
+        const bool ok = (b0 + i < RPW) && rr < NROWS;
+        const int row = ok ? rr : NROWS - 1;
+        const int c1 = row * TILE_R + 1;
+        la[i] = lstart[c1];
+        len[i] = ok ? lstart[c1 + 8] - la[i] : 0u;
+        const uint32_t ga = gstart[c1];
+        t0[i] = make_uint4(0, 0, 0, 0); t1[i] = make_uint4(0, 0, 0, 0);
+        if ((uint32_t)lane < len[i]) t0[i] = src4[ga + lane];
+        if ((uint32_t)lane + 64u < len[i]) t1[i] = src4[ga + lane + 64u];
+        long_rows |= len[i] > 128u;
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        if ((uint32_t)lane < len[i]) l4[la[i] + lane] = t0[i];
+        if ((uint32_t)lane + 64u < len[i]) l4[la[i] + lane + 64u] = t1[i];
+      }
     }
     const int g8 = threadIdx.x >> 3, l8 = threadIdx.x & 7;
     constexpr int NHALO = 2 * NROWS;
@@ -539,11 +549,6 @@ __global__ __launch_bounds__(TWG, 1) void knn_tile_kernel(GridParams gp, const R
       if ((uint32_t)l8 < hlen[i]) h0[i] = src4[ga + l8];
       if ((uint32_t)l8 + 8u < hlen[i]) h1[i] = src4[ga + l8 + 8u];
       long_cells |= hlen[i] > 16u;
-    }
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      if ((uint32_t)lane < len[i]) l4[la[i] + lane] = t0[i];
-      if ((uint32_t)lane + 64u < len[i]) l4[la[i] + lane + 64u] = t1[i];
     }
 #pragma unroll
     for (int i = 0; i < HC; ++i) {
@@ -816,16 +821,23 @@ template void pt_launch_knn<RecF>(const GridParams&, const RecF*, const uint32_t
 template void pt_launch_knn<RecD>(const GridParams&, const RecD*, const uint32_t*, const RecD*, uint32_t, int, const double*, uint32_t*, double*,
                                   const uint32_t*, const uint32_t*, hipStream_t);
 
-// tile kernel over all blocks; targets it cannot settle are appended to todo[*todo_n] (todo_n zeroed by the caller)
+// tile kernel over all blocks; targets it cannot settle are appended to todo[*todo_n] (todo_n zeroed by the caller).
+// `small` selects the two-workgroups-per-CU geometry (regions of <= 4480 records).
 void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* cell_start, const RecF* tgt, const uint32_t* tblock_start, int k,
-                        uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, hipStream_t s) {
+                        uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int small, hipStream_t s) {
   const uint32_t nb = (uint32_t)gp.nblocks;
-  if (k <= 8)
-    hipLaunchKernelGGL(knn_tile_kernel<8>, dim3(nb), dim3(TWG), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n);
-  else if (k <= 16)
-    hipLaunchKernelGGL(knn_tile_kernel<16>, dim3(nb), dim3(TWG), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n);
-  else
-    hipLaunchKernelGGL(knn_tile_kernel<32>, dim3(nb), dim3(TWG), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n);
+#define PT_TILE_LAUNCH(KK, CAP, TH) \
+  hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n)
+  if (small) {
+    if (k <= 8) PT_TILE_LAUNCH(8, 4480, 512);
+    else if (k <= 16) PT_TILE_LAUNCH(16, 4224, 512);
+    else PT_TILE_LAUNCH(32, 3968, 512);
+  } else {
+    if (k <= 8) PT_TILE_LAUNCH(8, 8448, 768);
+    else if (k <= 16) PT_TILE_LAUNCH(16, 8448, 768);
+    else PT_TILE_LAUNCH(32, 8448, 768);
+  }
+#undef PT_TILE_LAUNCH
 }
 
 void pt_launch_merge(const uint32_t* idx_lists, const double* d2_lists, int g, uint32_t m, int k, uint32_t* idx_out, double* d2_out,

@@ -86,6 +86,7 @@ int main(int argc, char** argv) {
     std::cerr << "pointsTransfer: no usable HIP device (pt_ctx_create returned " << rc << "); there is no CPU fallback" << std::endl;
     return 1;
   }
+  pt_set_param(ctx, "k_hint", (double)K);
   rc = pt_build_aos(ctx, reinterpret_cast<const pt_point*>(points.data()), points.size());
   if (rc != PT_OK) { std::cerr << "pointsTransfer: build failed: " << pt_last_error(ctx) << std::endl; pt_ctx_destroy(ctx); return 1; }
   std::cout << "Built Kd tree in: " << since(t_task) << " seconds" << std::endl;   // the line's wording is the contract

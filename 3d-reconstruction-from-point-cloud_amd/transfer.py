@@ -46,7 +46,7 @@ def _ptr(a):
 class PointsTransfer:
     """One context = one GPU = one (slab of a) source cloud."""
 
-    def __init__(self, device=0, rho=None):
+    def __init__(self, device=0, rho=None, k_hint=None):
         self._L = capi.lib()
         self._h = C.c_void_p()
         dev = (C.c_int * 1)(device)
@@ -54,6 +54,8 @@ class PointsTransfer:
         if rc != capi.OK:
             self._h = C.c_void_p()
             raise capi.PtError(rc, "pt_ctx_create failed (no usable gfx950 device? there is no CPU fallback)")
+        if k_hint is not None:
+            self.set_param("k_hint", k_hint)      # cell density suited to the k the queries will use
         if rho is not None:
             self.set_param("rho", rho)
 

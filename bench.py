@@ -143,7 +143,7 @@ def main():
         m_total = args.m
     axis = 0
     bounds = sharding.uniform_slab_bounds(world)
-    pt = pkg.PointsTransfer(device=local_rank)
+    pt = pkg.PointsTransfer(device=local_rank, k_hint=k)
     if world > 1:
         pt.build_synth(n_total, seed, slab_axis=axis, slab_lo=bounds[rank], slab_hi=bounds[rank + 1])
         pt.targets_synth(m_total, seed, slab_axis=axis, slab_lo=bounds[rank], slab_hi=bounds[rank + 1])

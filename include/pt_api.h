@@ -93,9 +93,11 @@ void pt_ctx_destroy(pt_ctx*);
  * kernels queue behind whatever produced the device buffers handed in.  NULL = HIP's default stream;
  * pt_set_param(ctx, "own_stream", 1) returns to the context's own (non-blocking) stream. */
 int  pt_set_stream(pt_ctx*, void* hip_stream);
-/* Tunables: "rho" (target points per grid cell, default 6), "sync" (1 = every call blocks until
- * the GPU is done, default 1; 0 = _dev calls only enqueue), "tile" (1 = tile kernel + group kernel for its
- * leftovers, default; 0 = group kernel only). */
+/* Tunables: "k_hint" (the k later queries will use: picks the cell density before a build; default 8), "rho" (points
+ * per grid cell, set directly; default 4), "sync" (1 = every call blocks until
+ * the GPU is done, default 1; 0 = _dev calls only enqueue), "tile" (0 = group kernel only, 1 = tile kernel +
+ * group kernel for its leftovers with the geometry chosen from the cell density (default), 2 / 3 = force the small /
+ * large tile geometry). */
 int  pt_set_param(pt_ctx*, const char* name, double value);
 const char* pt_last_error(pt_ctx*);
 int  pt_stats(pt_ctx*, pt_stats_t* out);

@@ -60,7 +60,7 @@ def test_tile_kernel_and_group_kernel_agree(pkg, oracle, k):
     bits as each other and as the oracle; the tile kernel may only hand a small share of the targets over."""
     src, tgt = oracle.synth_xyz(21, 0, 400000), oracle.synth_xyz(21, 1, 30000)
     want = oracle.KdTree(src).query(tgt, k)
-    with pkg.PointsTransfer(device=0) as p:
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
         p.build(src)
         p.set_param("tile", 1)
         got_tile = p.query(tgt, k)
@@ -70,7 +70,7 @@ def test_tile_kernel_and_group_kernel_agree(pkg, oracle, k):
         assert p.stats()["n_leftover"] == 0
     _check_exact(got_tile, want, "tile k=%d" % k)
     _check_exact(got_group, want, "group k=%d" % k)
-    assert left < 0.5 * tgt.shape[1], "tile kernel handed over %d of %d targets" % (left, tgt.shape[1])
+    assert left < 0.05 * tgt.shape[1], "tile kernel handed over %d of %d targets" % (left, tgt.shape[1])   # (k > 24: not used at all)
 
 
 def test_device_generator_matches_oracle(pkg, oracle):

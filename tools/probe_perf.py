@@ -8,7 +8,7 @@ cfgs = {"C2": (10_000_000, 1_000_000, 8, 0xC2), "C3": (100_000_000, 10_000_000, 
 names = sys.argv[1:] or ["C2", "C3", "C4"]
 for name in names:
     n, m, k, seed = cfgs[name]
-    with pkg.PointsTransfer(device=0) as p:
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
         t = time.time(); p.build_synth(n, seed); p.targets_synth(m, seed); print(name, "setup", round(time.time() - t, 3), flush=True)
         idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
         rgb = torch.empty((m, 3), dtype=torch.float32, device="cuda"); nrm = torch.empty((m, 3), dtype=torch.float32, device="cuda")
