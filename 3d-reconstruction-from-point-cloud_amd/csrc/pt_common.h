@@ -74,8 +74,9 @@ __device__ inline uint32_t wave_incl_scan(uint32_t v) {
   }
   return v;
 }
-// exclusive scan of one value per thread over a 256-thread workgroup; wsum: LDS scratch of 4 words
-__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* wsum, uint32_t& total) {
+// exclusive scan of one value per thread over a workgroup of NW waves; wsum: LDS scratch of NW words
+template <int NW>
+__device__ inline uint32_t block_excl_scan_n(uint32_t v, uint32_t* wsum, uint32_t& total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t incl = wave_incl_scan(v);
   __syncthreads();
@@ -84,12 +85,13 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* wsum, uint32_t&
   uint32_t off = 0;
   total = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NW; ++i) {
     const uint32_t ws = wsum[i];
     if (i < w) off += ws;
     total += ws;
   }
   return off + incl - v;
 }
+__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* wsum, uint32_t& total) { return block_excl_scan_n<4>(v, wsum, total); }
 
 #endif

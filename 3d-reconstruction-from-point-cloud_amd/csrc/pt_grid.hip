@@ -216,28 +216,28 @@ __global__ __launch_bounds__(WG) void hist_kernel(Loader in, GridParams gp, BinS
 }
 
 // ---- partition pass: scatter (one tile per workgroup) ----------------------------------------------
-template <class Loader, int ITEMS>
-__global__ __launch_bounds__(WG) void scatter_kernel(Loader in, typename Loader::Rec* __restrict__ out, GridParams gp, BinSpec bs,
+template <class Loader, int ITEMS, int SW>
+__global__ __launch_bounds__(SW) void scatter_kernel(Loader in, typename Loader::Rec* __restrict__ out, GridParams gp, BinSpec bs,
                                                      const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ tile_first, int nseg,
                                                      uint32_t* cursor) {
   using Rec = typename Loader::Rec;
-  constexpr uint32_t TILE = WG * ITEMS;
-  constexpr int BPT = PT_MAXBINS / WG;            // bins per thread in the scan
+  constexpr uint32_t TILE = SW * ITEMS;
+  constexpr int BPT = PT_MAXBINS / SW;            // bins per thread in the scan
   __shared__ uint32_t binA[PT_MAXBINS];           // counts, then local start of each bin in `stage`
   __shared__ uint32_t binB[PT_MAXBINS];           // global start of the bin's run minus its local start
-  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t wsum[SW / 64];
   __shared__ Rec stage[TILE];
 
   uint32_t seg, s, e;
   if (!tile_range(seg_start, tile_first, nseg, blockIdx.x, TILE, seg, s, e)) return;
-  for (int b = threadIdx.x; b < PT_MAXBINS; b += WG) binA[b] = 0;
+  for (int b = threadIdx.x; b < PT_MAXBINS; b += SW) binA[b] = 0;
   __syncthreads();
 
   Rec r[ITEMS];
   uint32_t lb[ITEMS], rank[ITEMS];
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
-    const uint32_t i = s + j * WG + threadIdx.x;
+    const uint32_t i = s + j * SW + threadIdx.x;
     if (i < e) {
       r[j] = in.load(i);
       lb[j] = local_bin(bs, block_of_rec(gp, r[j]));
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(WG) void scatter_kernel(Loader in, typename Loader:
 #pragma unroll
     for (int i = 0; i < BPT; ++i) { c[i] = binA[threadIdx.x * BPT + i]; sum += c[i]; }
     uint32_t tot;
-    uint32_t ex = block_excl_scan(sum, wsum, tot);
+    uint32_t ex = block_excl_scan_n<SW / 64>(sum, wsum, tot);
 #pragma unroll
     for (int i = 0; i < BPT; ++i) {
       const int b = threadIdx.x * BPT + i;
@@ -262,14 +262,14 @@ __global__ __launch_bounds__(WG) void scatter_kernel(Loader in, typename Loader:
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
-    const uint32_t i = s + j * WG + threadIdx.x;
+    const uint32_t i = s + j * SW + threadIdx.x;
     if (i < e) stage[binA[lb[j]] + rank[j]] = r[j];
   }
   __syncthreads();
   const uint32_t cnt = e - s;
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
-    const uint32_t slot = j * WG + threadIdx.x;
+    const uint32_t slot = j * SW + threadIdx.x;
     if (slot < cnt) {
       const Rec v = stage[slot];
       out[binB[local_bin(bs, block_of_rec(gp, v))] + slot] = v;     // consecutive slots of a bin -> consecutive addresses
@@ -317,29 +317,29 @@ __global__ __launch_bounds__(WG) void colapply_kernel(uint32_t* __restrict__ mat
     for (int r = r0; r < r1; ++r) { const uint32_t t = mat[(size_t)r * nbins + b]; mat[(size_t)r * nbins + b] = run; run += t; }
   }
 }
-template <class Loader, int ITEMS>
-__global__ __launch_bounds__(WG) void scatter_chunk_kernel(Loader in, typename Loader::Rec* __restrict__ out, GridParams gp, BinSpec bs, uint32_t n,
+template <class Loader, int ITEMS, int SW>
+__global__ __launch_bounds__(SW) void scatter_chunk_kernel(Loader in, typename Loader::Rec* __restrict__ out, GridParams gp, BinSpec bs, uint32_t n,
                                                            int chunk_tiles, const uint32_t* __restrict__ chunk_base) {
   using Rec = typename Loader::Rec;
-  constexpr uint32_t TILE = WG * ITEMS;
-  constexpr int BPT = PT_MAXBINS / WG;
+  constexpr uint32_t TILE = SW * ITEMS;
+  constexpr int BPT = PT_MAXBINS / SW;
   __shared__ uint32_t cursor[PT_MAXBINS];         // next free global slot of every bin, for this chunk
   __shared__ uint32_t binA[PT_MAXBINS];
   __shared__ uint32_t binB[PT_MAXBINS];
-  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t wsum[SW / 64];
   __shared__ Rec stage[TILE];
-  for (int b = threadIdx.x; b < PT_MAXBINS; b += WG) cursor[b] = b < bs.nbins ? chunk_base[(size_t)blockIdx.x * bs.nbins + b] : 0u;
+  for (int b = threadIdx.x; b < PT_MAXBINS; b += SW) cursor[b] = b < bs.nbins ? chunk_base[(size_t)blockIdx.x * bs.nbins + b] : 0u;
   for (int t = 0; t < chunk_tiles; ++t) {
     const uint64_t s64 = ((uint64_t)blockIdx.x * chunk_tiles + t) * TILE;
     if (s64 >= n) break;
     const uint32_t s = (uint32_t)s64, e = (uint32_t)min((uint64_t)n, s64 + TILE);
-    for (int b = threadIdx.x; b < PT_MAXBINS; b += WG) binA[b] = 0;
+    for (int b = threadIdx.x; b < PT_MAXBINS; b += SW) binA[b] = 0;
     __syncthreads();
     Rec r[ITEMS];
     uint32_t lb[ITEMS], rank[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-      const uint32_t i = s + j * WG + threadIdx.x;
+      const uint32_t i = s + j * SW + threadIdx.x;
       if (i < e) {
         r[j] = in.load(i);
         lb[j] = local_bin(bs, block_of_rec(gp, r[j]));
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(WG) void scatter_chunk_kernel(Loader in, typename L
 #pragma unroll
       for (int i = 0; i < BPT; ++i) { c[i] = binA[threadIdx.x * BPT + i]; sum += c[i]; }
       uint32_t tot;
-      uint32_t ex = block_excl_scan(sum, wsum, tot);
+      uint32_t ex = block_excl_scan_n<SW / 64>(sum, wsum, tot);
 #pragma unroll
       for (int i = 0; i < BPT; ++i) {
         const int b = threadIdx.x * BPT + i;
@@ -365,14 +365,14 @@ __global__ __launch_bounds__(WG) void scatter_chunk_kernel(Loader in, typename L
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-      const uint32_t i = s + j * WG + threadIdx.x;
+      const uint32_t i = s + j * SW + threadIdx.x;
       if (i < e) stage[binA[lb[j]] + rank[j]] = r[j];
     }
     __syncthreads();
     const uint32_t cnt = e - s;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-      const uint32_t slot = j * WG + threadIdx.x;
+      const uint32_t slot = j * SW + threadIdx.x;
       if (slot < cnt) {
         const Rec v = stage[slot];
         out[binB[local_bin(bs, block_of_rec(gp, v))] + slot] = v;
@@ -461,7 +461,7 @@ template <class Rec> constexpr int items_for() { return sizeof(Rec) == 16 ? 8 : 
 }  // namespace
 
 // =================================================================================================
-int pt_sort_tile_points(size_t rec_size) { return WG * (rec_size == 16 ? 8 : 4); }
+int pt_sort_tile_points(size_t rec_size) { return rec_size == 16 ? 4096 : 2048; }   // 64 KB of records per scatter tile
 // tiles per pass-1 chunk: enough chunks to fill the chip, few enough that the chunk-histogram table stays small
 int pt_sort_chunk_tiles(uint32_t n, size_t rec_size) {
   const uint32_t tile = (uint32_t)pt_sort_tile_points(rec_size);
@@ -501,8 +501,10 @@ void pt_launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t*
 template <class T, class Rec>
 void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* z, const uint32_t* gidx, uint32_t n, Rec* out_final,
                          Rec* tmp, uint32_t* cell_start, const SortTables& tb, hipStream_t s) {
-  constexpr int ITEMS = items_for<Rec>();
-  constexpr uint32_t TILE = WG * ITEMS;
+  constexpr int SW = 512;                              // scatter workgroup: 8 waves, 64 KB of staged records, 2 per CU
+  constexpr int ITEMS_S = items_for<Rec>();            // records per scatter thread (8 / 4)
+  constexpr int ITEMS = ITEMS_S * (SW / WG);           // records per histogram thread (same tile, 256 threads)
+  constexpr uint32_t TILE = SW * ITEMS_S;
   const uint32_t nblocks = (uint32_t)gp.nblocks;
   const uint32_t nmacro = nblocks / PT_MACRO_BLOCKS;
   const uint32_t ntiles = (n + TILE - 1) / TILE;
@@ -526,7 +528,7 @@ void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* 
     (void)hipMemcpyAsync(tb.cursor2, tb.block_start, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s);
     mark(1); mark(2); mark(3);
     if (n)
-      hipLaunchKernelGGL((scatter_kernel<PlanarLoader<T>, ITEMS>), dim3(ntiles), dim3(WG), 0, s, pl, tmp, gp, bs, tb.seg_start1,
+      hipLaunchKernelGGL((scatter_kernel<PlanarLoader<T>, ITEMS_S, SW>), dim3(ntiles), dim3(SW), 0, s, pl, tmp, gp, bs, tb.seg_start1,
                          tb.tile_first1, 1, tb.cursor2);
     mark(4);
     blocked = tmp;
@@ -550,7 +552,7 @@ void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* 
   mark(1);
   if (n) {
     hipLaunchKernelGGL(colapply_kernel, dim3(ngroups), dim3(WG), 0, s, tb.chunk_hist, (int)nchunks, (int)nmacro, tb.chunk_gsum, tb.start1);
-    hipLaunchKernelGGL((scatter_chunk_kernel<PlanarLoader<T>, ITEMS>), dim3(nchunks), dim3(WG), 0, s, pl, out_final, gp, b1, n, chunk_tiles,
+    hipLaunchKernelGGL((scatter_chunk_kernel<PlanarLoader<T>, ITEMS_S, SW>), dim3(nchunks), dim3(SW), 0, s, pl, out_final, gp, b1, n, chunk_tiles,
                        tb.chunk_hist);
   }
   mark(2);
@@ -565,7 +567,7 @@ void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* 
   (void)hipMemcpyAsync(tb.cursor2, tb.block_start, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s);
   mark(3);
   if (n)
-    hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS>), dim3(ntiles2), dim3(WG), 0, s, rl, tmp, gp, b2, tb.start1, tb.tile_first2,
+    hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS_S, SW>), dim3(ntiles2), dim3(SW), 0, s, rl, tmp, gp, b2, tb.start1, tb.tile_first2,
                        (int)nmacro, tb.cursor2);
   mark(4);
   hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start);
