@@ -174,7 +174,7 @@ template <class T, class Rec>
 int run_source_sort(pt_ctx* c) {
   const T* x = (const T*)c->in_xyz.p;
   pt_launch_grid_sort<T, Rec>(c->gp, x, x + c->n, x + 2 * c->n, c->has_gidx ? (const uint32_t*)c->in_gidx.p : nullptr, (uint32_t)c->n,
-                              (Rec*)c->rec.p, (Rec*)c->rec_tmp.p, (uint32_t*)c->cell_start.p, c->stb, c->stream);
+                              (Rec*)c->rec.p, (Rec*)c->rec_tmp.p, (uint32_t*)c->cell_start.p, c->stb, true, c->stream);
   return PT_OK;
 }
 
@@ -254,7 +254,8 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (ttype == PT_F32) {
     const float* x = (const float*)txyz;
-    pt_launch_grid_sort<float, RecF>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecF*)c->trec.p, (RecF*)c->trec_tmp.p, nullptr, c->ttb, c->stream);
+    // targets only need to be grouped by block (tile kernel) -- the cell-level pass is skipped
+    const RecF* tsorted = pt_launch_grid_sort<float, RecF>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecF*)c->trec.p, (RecF*)c->trec_tmp.p, nullptr, c->ttb, false, c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (c->tile && !bound2_dev && m && k <= 24) {     // beyond k = 24 a region that holds ring 1 no longer fits LDS
       // regions (10^3 cells) that fit 4480 records with headroom run the two-workgroups-per-CU geometry
@@ -262,20 +263,20 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
       const int tile_small = c->tile == 2 || (c->tile == 1 && (double)c->n / cells * 1000.0 * 1.05 <= (k <= 8 ? 4480.0 : (k <= 16 ? 4224.0 : 3968.0)));
       uint32_t* todo_n = (uint32_t*)c->counter.p + 4;
       HIPCHK(c, hipMemsetAsync(todo_n, 0, 4, c->stream));
-      pt_launch_knn_tile(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecF*)c->trec.p, c->ttb.block_start, k, idx_dev, d2_dev,
+      pt_launch_knn_tile(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, c->ttb.block_start, k, idx_dev, d2_dev,
                          (uint32_t*)c->todo.p, todo_n, tile_small, c->stream);
-      pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecF*)c->trec.p, m, k, nullptr, idx_dev, d2_dev,
+      pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, nullptr, idx_dev, d2_dev,
                           (const uint32_t*)c->todo.p, todo_n, c->stream);
       HIPCHK(c, hipMemcpyAsync(c->h_counter + 4, todo_n, 4, hipMemcpyDeviceToHost, c->stream));
     } else {
-      pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecF*)c->trec.p, m, k, bound2_dev, idx_dev, d2_dev,
+      pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, bound2_dev, idx_dev, d2_dev,
                           nullptr, nullptr, c->stream);
     }
   } else {
     const double* x = (const double*)txyz;
-    pt_launch_grid_sort<double, RecD>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecD*)c->trec.p, (RecD*)c->trec_tmp.p, nullptr, c->ttb, c->stream);
+    const RecD* tsorted = pt_launch_grid_sort<double, RecD>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecD*)c->trec.p, (RecD*)c->trec_tmp.p, nullptr, c->ttb, false, c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, (const RecD*)c->trec.p, m, k, bound2_dev, idx_dev, d2_dev,
+    pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, bound2_dev, idx_dev, d2_dev,
                         nullptr, nullptr, c->stream);
   }
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));

@@ -499,8 +499,8 @@ void pt_launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t*
 }
 
 template <class T, class Rec>
-void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* z, const uint32_t* gidx, uint32_t n, Rec* out_final,
-                         Rec* tmp, uint32_t* cell_start, const SortTables& tb, hipStream_t s) {
+const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* z, const uint32_t* gidx, uint32_t n, Rec* out_final,
+                               Rec* tmp, uint32_t* cell_start, const SortTables& tb, bool do_finalize, hipStream_t s) {
   constexpr int SW = 512;                              // scatter workgroup: 8 waves, 64 KB of staged records, 2 per CU
   constexpr int ITEMS_S = items_for<Rec>();            // records per scatter thread (8 / 4)
   constexpr int ITEMS = ITEMS_S * (SW / WG);           // records per histogram thread (same tile, 256 threads)
@@ -532,9 +532,9 @@ void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* 
                          tb.tile_first1, 1, tb.cursor2);
     mark(4);
     blocked = tmp;
-    hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, blocked, out_final, gp, tb.block_start, cell_start);
+    if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, blocked, out_final, gp, tb.block_start, cell_start);
     mark(5);
-    return;
+    return do_finalize ? out_final : tmp;
   }
   // two levels: planar -> out_final (by macro block) -> tmp (by block) -> out_final (by cell)
   const BinSpec b1{0, 9, (int)nmacro};
@@ -570,10 +570,11 @@ void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* 
     hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS_S, SW>), dim3(ntiles2), dim3(SW), 0, s, rl, tmp, gp, b2, tb.start1, tb.tile_first2,
                        (int)nmacro, tb.cursor2);
   mark(4);
-  hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start);
+  if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start);
   mark(5);
+  return do_finalize ? out_final : tmp;
 }
-template void pt_launch_grid_sort<float, RecF>(const GridParams&, const float*, const float*, const float*, const uint32_t*, uint32_t, RecF*,
-                                               RecF*, uint32_t*, const SortTables&, hipStream_t);
-template void pt_launch_grid_sort<double, RecD>(const GridParams&, const double*, const double*, const double*, const uint32_t*, uint32_t,
-                                                RecD*, RecD*, uint32_t*, const SortTables&, hipStream_t);
+template const RecF* pt_launch_grid_sort<float, RecF>(const GridParams&, const float*, const float*, const float*, const uint32_t*, uint32_t, RecF*,
+                                                      RecF*, uint32_t*, const SortTables&, bool, hipStream_t);
+template const RecD* pt_launch_grid_sort<double, RecD>(const GridParams&, const double*, const double*, const double*, const uint32_t*, uint32_t,
+                                                       RecD*, RecD*, uint32_t*, const SortTables&, bool, hipStream_t);

@@ -27,12 +27,13 @@ void pt_launch_bbox_init(uint64_t* out6, hipStream_t s);
 template <class T> void pt_launch_bbox(const T* x, const T* y, const T* z, uint32_t n, uint64_t* out6, hipStream_t s);
 double pt_bbox_decode(uint64_t enc);
 
-// Sort n points into cell order.  Input either planar (x,y,z[,gidx]) or records; output `out_final`
-// sorted by cell key, `tmp` is scratch of the same size.  cell_start (u32[nblocks*512+1]) is written when
-// non-null.  Rec = RecF (T=float) or RecD (T=double).
+// Sort n points into cell order.  Planar input (x,y,z[,gidx]); `out_final` and `tmp` are record buffers of n entries.
+// With do_finalize the result is sorted by cell key and cell_start (u32[nblocks*512+1]) is written when non-null;
+// without it the records are only grouped by 8^3-cell block (tb.block_start delimits the groups) -- all the tile
+// kernel needs of the TARGETS.  Returns the buffer that holds the result.  Rec = RecF (T=float) or RecD (T=double).
 template <class T, class Rec>
-void pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* z, const uint32_t* gidx, uint32_t n,
-                         Rec* out_final, Rec* tmp, uint32_t* cell_start, const SortTables& tb, hipStream_t s);
+const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* z, const uint32_t* gidx, uint32_t n,
+                               Rec* out_final, Rec* tmp, uint32_t* cell_start, const SortTables& tb, bool do_finalize, hipStream_t s);
 int pt_sort_tile_points(size_t rec_size);
 int pt_sort_chunk_tiles(uint32_t n, size_t rec_size);
 uint32_t pt_sort_num_chunks(uint32_t n, size_t rec_size);
