@@ -470,7 +470,7 @@ int pt_build_soa(pt_ctx* c, const void* xyz, int xyz_type, const uint8_t* rgb, c
 
 int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz_type, int slab_axis, double slab_lo, double slab_hi) {
   if (!c) return PT_ERR_ARG;
-  if (dist != PT_DIST_UNIFORM) return fail(c, PT_ERR_UNSUPPORTED, "only the uniform generator is implemented");
+  if (dist != PT_DIST_UNIFORM && dist != PT_DIST_CLUSTERED) return fail(c, PT_ERR_ARG, "unknown distribution %d", dist);
   if (xyz_type != PT_F32 && xyz_type != PT_F64 && xyz_type != PT_F16) return fail(c, PT_ERR_ARG, "unknown xyz_type %d", xyz_type);
   const int f16 = xyz_type == PT_F16;      // fp16 values, held widened as fp32 on the device
   if (f16) xyz_type = PT_F32;
@@ -481,7 +481,7 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
   const bool slab = slab_axis >= 0;
   if (slab) {   // counting pass
     HIPCHK(c, hipMemsetAsync(c->counter.p, 0, 4, c->stream));
-    pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, nullptr, nullptr, nullptr, nullptr, (uint32_t*)c->counter.p, 0, f16, c->stream);
+    pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, nullptr, nullptr, nullptr, nullptr, (uint32_t*)c->counter.p, 0, f16, dist, n_total, 0, c->stream);
     HIPCHK(c, hipMemcpyAsync(c->h_counter, c->counter.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     n = *c->h_counter;
@@ -490,8 +490,8 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
   }
   RES(c, c->in_xyz, std::max<uint64_t>(n, 1) * 3 * tsize(xyz_type));
   uint32_t* g = slab ? (uint32_t*)c->in_gidx.p : nullptr;
-  if (xyz_type == PT_F32) { float* x = (float*)c->in_xyz.p; pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, c->stream); }
-  else { double* x = (double*)c->in_xyz.p; pt_launch_synth_xyz<double>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, c->stream); }
+  if (xyz_type == PT_F32) { float* x = (float*)c->in_xyz.p; pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream); }
+  else { double* x = (double*)c->in_xyz.p; pt_launch_synth_xyz<double>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream); }
   RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
   pt_launch_synth_attr(seed, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
   c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false;
@@ -506,18 +506,19 @@ int pt_rebuild(pt_ctx* c) {
 // ---- query ----------------------------------------------------------------------------------------
 int pt_targets_synth(pt_ctx* c, uint64_t m_total, uint64_t seed, int dist, int xyz_type, int slab_axis, double slab_lo, double slab_hi) {
   if (!c) return PT_ERR_ARG;
-  if (dist != PT_DIST_UNIFORM) return fail(c, PT_ERR_UNSUPPORTED, "only the uniform generator is implemented");
+  if (dist != PT_DIST_UNIFORM && dist != PT_DIST_CLUSTERED) return fail(c, PT_ERR_ARG, "unknown distribution %d", dist);
   if (xyz_type != PT_F32 && xyz_type != PT_F64 && xyz_type != PT_F16) return fail(c, PT_ERR_ARG, "unknown xyz_type %d", xyz_type);
   const int f16 = xyz_type == PT_F16;
   if (f16) xyz_type = PT_F32;
   if (slab_axis > 2) return fail(c, PT_ERR_ARG, "slab_axis must be < 3");
+  if (dist == PT_DIST_CLUSTERED && c->src_type < 0) return fail(c, PT_ERR_STATE, "clustered targets are a subsample of the sources: build the cloud first");
   { int r = check_n(c, m_total, "m_total"); if (r) return r; }
   HIPCHK(c, hipSetDevice(c->device));
   uint64_t m = m_total;
   const bool slab = slab_axis >= 0;
   if (slab) {
     HIPCHK(c, hipMemsetAsync(c->counter.p, 0, 4, c->stream));
-    pt_launch_synth_xyz<float>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, nullptr, nullptr, nullptr, nullptr, (uint32_t*)c->counter.p, 0, f16, c->stream);
+    pt_launch_synth_xyz<float>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, nullptr, nullptr, nullptr, nullptr, (uint32_t*)c->counter.p, 0, f16, dist, c->n_total, m_total, c->stream);
     HIPCHK(c, hipMemcpyAsync(c->h_counter, c->counter.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     m = *c->h_counter;
@@ -526,8 +527,8 @@ int pt_targets_synth(pt_ctx* c, uint64_t m_total, uint64_t seed, int dist, int x
   RES(c, c->t_gidx, std::max<uint64_t>(m, 1) * sizeof(uint32_t));
   RES(c, c->t_xyz, std::max<uint64_t>(m, 1) * 3 * tsize(xyz_type));
   uint32_t* g = (uint32_t*)c->t_gidx.p;
-  if (xyz_type == PT_F32) { float* x = (float*)c->t_xyz.p; pt_launch_synth_xyz<float>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, x, x + m, x + 2 * m, g, (uint32_t*)c->counter.p, (uint32_t)m, f16, c->stream); }
-  else { double* x = (double*)c->t_xyz.p; pt_launch_synth_xyz<double>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, x, x + m, x + 2 * m, g, (uint32_t*)c->counter.p, (uint32_t)m, f16, c->stream); }
+  if (xyz_type == PT_F32) { float* x = (float*)c->t_xyz.p; pt_launch_synth_xyz<float>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, x, x + m, x + 2 * m, g, (uint32_t*)c->counter.p, (uint32_t)m, f16, dist, c->n_total, m_total, c->stream); }
+  else { double* x = (double*)c->t_xyz.p; pt_launch_synth_xyz<double>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, x, x + m, x + 2 * m, g, (uint32_t*)c->counter.p, (uint32_t)m, f16, dist, c->n_total, m_total, c->stream); }
   c->tgt_type = xyz_type; c->m = m; c->t_has_gidx = true;
   return finish(c);
 }

@@ -23,15 +23,63 @@ __host__ __device__ inline uint64_t splitmix64(uint64_t z) {
 __host__ __device__ inline uint64_t stream_key(uint64_t seed, uint64_t stream) { return splitmix64(seed ^ (stream << 56)); }
 __device__ inline float u24(uint64_t h) { return (float)(uint32_t)(h >> 40) * (1.0f / 16777216.0f); }
 
+// clustered distribution (BASELINE config 5): the same arithmetic, op for op, as the CPU checker's generator
+__device__ inline float gauss4(uint64_t h) {
+  const uint64_t a = splitmix64(h), b = splitmix64(a), c = splitmix64(b), d = splitmix64(c);
+  return ((u24(a) + u24(b)) + (u24(c) + u24(d)) - 2.0f) * 1.7320508f;
+}
+__device__ inline float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 0.99999994f ? 0.99999994f : v); }
+__device__ inline void clustered_source(uint64_t seed, uint64_t i, float (&out)[3]) {
+  const uint64_t k0 = stream_key(seed, 0), k4 = stream_key(seed, 4);
+  const uint64_t sel = splitmix64(k4 + 4ull * i);
+  const uint32_t t = (uint32_t)(sel % 100u);
+  const float ua = u24(splitmix64(k0 + 4ull * i + 0)), ub = u24(splitmix64(k0 + 4ull * i + 1));
+  const uint64_t hc = splitmix64(k0 + 4ull * i + 2);
+  if (t < 70u) {
+    const uint64_t p = (sel >> 8) % 64u, kp = stream_key(seed, 5);
+    const float g = gauss4(hc);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float o = u24(splitmix64(kp + 4ull * p + (uint64_t)c));
+      const float e1 = (2.0f * u24(splitmix64(kp + 4ull * (64u + p) + (uint64_t)c)) - 1.0f) * 0.3f;
+      const float e2 = (2.0f * u24(splitmix64(kp + 4ull * (128u + p) + (uint64_t)c)) - 1.0f) * 0.3f;
+      const float nn = 2.0f * u24(splitmix64(kp + 4ull * (192u + p) + (uint64_t)c)) - 1.0f;
+      out[c] = clamp01(((o + ua * e1) + ub * e2) + (1e-4f * g) * nn);
+    }
+  } else if (t < 95u) {
+    const uint64_t q = (sel >> 8) % 256u, kq = stream_key(seed, 6);
+    const float sigma = 1e-3f + 1.9e-2f * u24(splitmix64(kq + 4ull * q + 3));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = clamp01(u24(splitmix64(kq + 4ull * q + (uint64_t)c)) + sigma * gauss4(splitmix64(hc + (uint64_t)c)));
+  } else {
+    out[0] = ua; out[1] = ub; out[2] = u24(hc);
+  }
+}
+
 template <class T>
 __global__ __launch_bounds__(WG) void synth_xyz_kernel(uint64_t key, uint32_t n_total, int axis, double lo, double hi, T* __restrict__ x,
                                                        T* __restrict__ y, T* __restrict__ z, uint32_t* __restrict__ gidx, uint32_t* counter,
-                                                       uint32_t capacity, int round_f16) {
+                                                       uint32_t capacity, int round_f16, int dist, uint64_t seed, int stream,
+                                                       uint64_t src_total, uint64_t tgt_total) {
+#pragma clang fp contract(off)
   const uint32_t i = blockIdx.x * WG + threadIdx.x;
   if (i >= n_total) return;
-  float px = u24(splitmix64(key + 4ull * i + 0));
-  float py = u24(splitmix64(key + 4ull * i + 1));
-  float pz = u24(splitmix64(key + 4ull * i + 2));
+  float px, py, pz;
+  if (dist == 0) {
+    px = u24(splitmix64(key + 4ull * i + 0));
+    py = u24(splitmix64(key + 4ull * i + 1));
+    pz = u24(splitmix64(key + 4ull * i + 2));
+  } else {
+    float p[3];
+    if (stream == 0) clustered_source(seed, i, p);
+    else {
+      const uint64_t step = (tgt_total && src_total / tgt_total) ? src_total / tgt_total : 1;
+      clustered_source(seed, ((uint64_t)i * step) % (src_total ? src_total : 1), p);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) p[c] = clamp01(p[c] + 5e-4f * gauss4(splitmix64(splitmix64(key + 4ull * i + (uint64_t)c))));
+    }
+    px = p[0]; py = p[1]; pz = p[2];
+  }
   if (round_f16) {   // BASELINE config 5: xyz = half_rn(fp32 value), widened back exactly
     px = __half2float(__float2half_rn(px)); py = __half2float(__float2half_rn(py)); pz = __half2float(__float2half_rn(pz));
   }
@@ -206,15 +254,15 @@ inline dim3 grid_for(uint32_t n) { return dim3((n + WG - 1) / WG); }
 
 template <class T>
 void pt_launch_synth_xyz(uint64_t seed, uint64_t stream, uint32_t n_total, int axis, double lo, double hi, T* x, T* y, T* z, uint32_t* gidx,
-                         uint32_t* counter, uint32_t capacity, int round_f16, hipStream_t s) {
+                         uint32_t* counter, uint32_t capacity, int round_f16, int dist, uint64_t src_total, uint64_t tgt_total, hipStream_t s) {
   if (!n_total) return;
   hipLaunchKernelGGL(synth_xyz_kernel<T>, grid_for(n_total), dim3(WG), 0, s, stream_key(seed, stream), n_total, axis, lo, hi, x, y, z, gidx,
-                     counter, capacity, round_f16);
+                     counter, capacity, round_f16, dist, seed, (int)stream, src_total, tgt_total);
 }
 template void pt_launch_synth_xyz<float>(uint64_t, uint64_t, uint32_t, int, double, double, float*, float*, float*, uint32_t*, uint32_t*, uint32_t,
-                                         int, hipStream_t);
+                                         int, int, uint64_t, uint64_t, hipStream_t);
 template void pt_launch_synth_xyz<double>(uint64_t, uint64_t, uint32_t, int, double, double, double*, double*, double*, uint32_t*, uint32_t*,
-                                          uint32_t, int, hipStream_t);
+                                          uint32_t, int, int, uint64_t, uint64_t, hipStream_t);
 
 void pt_launch_synth_attr(uint64_t seed, uint32_t n_total, Attr* attr, hipStream_t s) {
   if (!n_total) return;

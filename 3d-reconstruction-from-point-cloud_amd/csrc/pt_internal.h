@@ -61,7 +61,8 @@ void pt_launch_slab_need(const T* x, const T* y, const T* z, const double* d2, u
 // in [lo,hi) to x/y/z/gidx, appending through *counter (device u32, zeroed by the caller).
 template <class T>
 void pt_launch_synth_xyz(uint64_t seed, uint64_t stream, uint32_t n_total, int axis, double lo, double hi, T* x, T* y, T* z,
-                         uint32_t* gidx, uint32_t* counter, uint32_t capacity, int round_f16, hipStream_t s);
+                         uint32_t* gidx, uint32_t* counter, uint32_t capacity, int round_f16, int dist, uint64_t src_total,
+                         uint64_t tgt_total, hipStream_t s);
 void pt_launch_half_to_float(const void* in_half, float* out, uint64_t count, hipStream_t s);
 void pt_launch_synth_attr(uint64_t seed, uint32_t n_total, Attr* attr, hipStream_t s);
 // reference AoS records (80-B stride, device copy) -> planar f64 xyz + attribute table

@@ -130,7 +130,9 @@ int  pt_query_aos(pt_ctx*, const pt_point* targets, uint64_t m, int k, uint32_t*
 int  pt_query_soa(pt_ctx*, const void* xyz, int xyz_type, uint64_t m, int k, int on_device,
                   uint32_t* idx, double* d2_or_null);
 /* Generate m targets on the device (stream 1 of the generator) into the context; query them with
- * pt_query_resident.  tgt_lo/hi restrict to targets whose slab_axis coordinate is in [lo,hi). */
+ * pt_query_resident.  tgt_lo/hi restrict to targets whose slab_axis coordinate is in [lo,hi).  The clustered
+ * distribution derives targets from the sources (strided subsample + jitter): call it after a pt_build_synth with
+ * the same seed. */
 int  pt_targets_synth(pt_ctx*, uint64_t m_total, uint64_t seed, int dist, int xyz_type,
                       int slab_axis, double slab_lo, double slab_hi);
 uint64_t pt_num_targets(pt_ctx*);

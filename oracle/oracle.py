@@ -39,6 +39,7 @@ def lib():
         L.pto_splitmix64.restype = u64
         L.pto_splitmix64.argtypes = [u64]
         L.pto_synth_xyz_f32.argtypes = [u64, u64, u64, u64, p]
+        L.pto_synth_xyz_dist.argtypes = [u64, u64, i32, u64, u64, u64, u64, p]
         L.pto_synth_rgb.argtypes = [u64, u64, u64, p]
         L.pto_synth_nrm.argtypes = [u64, u64, u64, p]
         for f in ("pto_transformed_distance",):
@@ -77,9 +78,13 @@ def _planar64(xyz):
 
 
 # ---- generator -------------------------------------
-def synth_xyz(seed, stream, n, i0=0):
+def synth_xyz(seed, stream, n, i0=0, dist=0, n_total=0, m_total=0):
+    """dist 0 uniform, 1 clustered (targets, stream 1, need the total source / target counts)."""
     out = np.empty((3, n), dtype=np.float32)
-    lib().pto_synth_xyz_f32(seed, stream, i0, n, _ptr(out))
+    if dist == 0:
+        lib().pto_synth_xyz_f32(seed, stream, i0, n, _ptr(out))
+    else:
+        lib().pto_synth_xyz_dist(seed, stream, dist, i0, n, n_total or n, m_total or n, _ptr(out))
     return out
 
 

@@ -62,6 +62,57 @@ void pto_synth_xyz_f32(uint64_t seed, uint64_t stream, uint64_t i0, uint64_t n, 
     xyz[2 * n + j] = u24(hash4(key, i, 2));
   }
 }
+/* ---- clustered distribution (BASELINE config 5; SURVEY.md Appendix C, frozen here) ------------------------------
+ * 70 % thin planar patches (64 of them), 25 % Gaussian-ish blobs (256, sigma in [1e-3, 2e-2]), 5 % uniform; targets are a
+ * strided subsample of the sources plus 5e-4 jitter.  Only +, -, * on floats and exact int->float conversions, each
+ * individually rounded (-ffp-contract=off), so the HIP generator produces the same bits. */
+static inline float gauss4(uint64_t h) {          /* Irwin-Hall(4), unit variance */
+  const uint64_t a = splitmix64(h), b = splitmix64(a), c = splitmix64(b), d = splitmix64(c);
+  return ((u24(a) + u24(b)) + (u24(c) + u24(d)) - 2.0f) * 1.7320508f;
+}
+static inline float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 0.99999994f ? 0.99999994f : v); }
+static void clustered_source(uint64_t seed, uint64_t i, float* out) {
+  const uint64_t k0 = stream_key(seed, 0), k4 = stream_key(seed, 4);
+  const uint64_t sel = hash4(k4, i, 0);
+  const uint32_t t = (uint32_t)(sel % 100u);
+  const float ua = u24(hash4(k0, i, 0)), ub = u24(hash4(k0, i, 1));
+  const uint64_t hc = hash4(k0, i, 2);
+  if (t < 70u) {
+    const uint64_t p = (sel >> 8) % 64u, kp = stream_key(seed, 5);
+    const float g = gauss4(hc);
+    for (int c = 0; c < 3; ++c) {
+      const float o = u24(hash4(kp, p, (uint64_t)c));
+      const float e1 = (2.0f * u24(hash4(kp, 64u + p, (uint64_t)c)) - 1.0f) * 0.3f;
+      const float e2 = (2.0f * u24(hash4(kp, 128u + p, (uint64_t)c)) - 1.0f) * 0.3f;
+      const float nn = 2.0f * u24(hash4(kp, 192u + p, (uint64_t)c)) - 1.0f;
+      out[c] = clamp01(((o + ua * e1) + ub * e2) + (1e-4f * g) * nn);
+    }
+  } else if (t < 95u) {
+    const uint64_t q = (sel >> 8) % 256u, kq = stream_key(seed, 6);
+    const float sigma = 1e-3f + 1.9e-2f * u24(hash4(kq, q, 3));
+    for (int c = 0; c < 3; ++c) out[c] = clamp01(u24(hash4(kq, q, (uint64_t)c)) + sigma * gauss4(splitmix64(hc + (uint64_t)c)));
+  } else {
+    out[0] = ua; out[1] = ub; out[2] = u24(hc);
+  }
+}
+/* dist 0 = uniform (as pto_synth_xyz_f32), 1 = clustered; stream 0 = sources, 1 = targets (needs n_total, m_total) */
+void pto_synth_xyz_dist(uint64_t seed, uint64_t stream, int dist, uint64_t i0, uint64_t n, uint64_t n_total, uint64_t m_total,
+                        float* xyz /* planar [3][n] */) {
+  if (dist == 0) { pto_synth_xyz_f32(seed, stream, i0, n, xyz); return; }
+  const uint64_t k1 = stream_key(seed, 1);
+  const uint64_t step = (m_total && n_total / m_total) ? n_total / m_total : 1;
+  for (uint64_t j = 0; j < n; ++j) {
+    float p[3];
+    if (stream == 0) clustered_source(seed, i0 + j, p);
+    else {
+      const uint64_t t = i0 + j;
+      clustered_source(seed, (t * step) % (n_total ? n_total : 1), p);
+      for (int c = 0; c < 3; ++c) p[c] = clamp01(p[c] + 5e-4f * gauss4(splitmix64(hash4(k1, t, (uint64_t)c))));
+    }
+    xyz[j] = p[0]; xyz[n + j] = p[1]; xyz[2 * n + j] = p[2];
+  }
+}
+
 /* colour = bytes 0,1,2 of h(seed,2,i,0); rgb is interleaved [n][3] */
 void pto_synth_rgb(uint64_t seed, uint64_t i0, uint64_t n, uint8_t* rgb) {
   const uint64_t key = stream_key(seed, 2);

@@ -263,6 +263,32 @@ def test_cli_end_to_end(tmp_path, pkg, oracle):
     assert np.abs(col - np.floor(rc)).max() <= 1                           # float -> uchar truncation, as the reference's rasteriser
 
 
+@pytest.mark.parametrize("xyz_type,k", [("f32", 8), ("f16", 32)])
+def test_clustered_distribution(pkg, oracle, xyz_type, k):
+    """BASELINE config 5's shape at test size: clustered density (thin patches + blobs + a little uniform), targets a
+    jittered subsample of the sources, fp16 coordinates with k = 32.  The device generator must reproduce the oracle's bits,
+    and the (slow on this distribution, but exact) search must match the oracle."""
+    import torch
+    n, m, seed = 300000, 15000, 0xC5
+    t = pkg.F16 if xyz_type == "f16" else pkg.F32
+    src = oracle.synth_xyz(seed, 0, n, dist=1)
+    tgt = oracle.synth_xyz(seed, 1, m, dist=1, n_total=n, m_total=m)
+    if xyz_type == "f16":
+        src = src.astype(np.float16).astype(np.float32); tgt = tgt.astype(np.float16).astype(np.float32)
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.build_synth(n, seed, xyz_type=t, dist=pkg.capi.DIST_CLUSTERED)
+        p.targets_synth(m, seed, xyz_type=t, dist=pkg.capi.DIST_CLUSTERED)
+        xyz = torch.empty((3, m), dtype=torch.float32, device="cuda")
+        p.resident_target_xyz_dev(xyz)
+        assert np.array_equal(xyz.cpu().numpy(), tgt), "clustered target generator differs from the oracle's"
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        p.query_resident_dev(k, idx, d2)
+        torch.cuda.synchronize()
+    want = oracle.KdTree(src).query(tgt, k)
+    _check_exact((idx.cpu().numpy().view(np.uint32), d2.cpu().numpy()), want, "clustered %s k=%d" % (xyz_type, k))
+    assert 0.0 <= src.min() and src.max() <= 1.0          # (fp16 rounding can reach 1.0 exactly)
+
+
 # ---- blend and PCA -------------------------------------------------------------------------------------------
 def test_blend_modes_match_golden(pt, oracle, golden, golden_cases):
     src, tgt = golden_cases["c1"]

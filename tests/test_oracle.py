@@ -20,6 +20,23 @@ def test_generator_kats(oracle, golden):
     assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-6)
 
 
+def test_clustered_generator_shape(oracle):
+    n, m = 50000, 2500
+    src = oracle.synth_xyz(0xC5, 0, n, dist=1)
+    tgt = oracle.synth_xyz(0xC5, 1, m, dist=1, n_total=n, m_total=m)
+    assert src.min() >= 0 and src.max() < 1 and tgt.min() >= 0 and tgt.max() < 1
+    # clustered: the occupancy of a 32^3 grid is far below what uniform points would give
+    occ = len(np.unique(np.array([1, 32, 1024]) @ (src * 32).astype(np.int64)))
+    uni = len(np.unique(np.array([1, 32, 1024]) @ (oracle.synth_xyz(0xC5, 0, n) * 32).astype(np.int64)))
+    assert occ < 0.6 * uni
+    # targets sit next to the sources they were drawn from (jitter 5e-4 * unit-variance noise)
+    step = n // m
+    d = np.abs(tgt - src[:, (np.arange(m) * step) % n]).max()
+    assert d < 5e-3
+    # index-addressable
+    assert np.array_equal(oracle.synth_xyz(0xC5, 0, 100, i0=777, dist=1), src[:, 777:877])
+
+
 def test_distance_known_answers(oracle):
     # reference src/Distance.h:6-11, :27-57, :60-90, :92-95, :97, :99 -- values from SURVEY.md 8c
     assert oracle.transformed_distance([0, 0, 0], [1, 2, 3]) == 14.0
