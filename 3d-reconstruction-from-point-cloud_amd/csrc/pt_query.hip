@@ -8,7 +8,12 @@
 // Cell pruning is Distance::min_distance_to_rectangle (reference src/Distance.h:27-57) applied to cell
 // boxes; ring termination is the same bound applied to the faces of the box already scanned.
 //
-// Mapping onto the wave: 8 lanes per target, 8 targets per wave64, 32 per 256-thread workgroup.
+// Two kernels, both exact:
+//   knn_tile_kernel  (second half of this file) fp32 clouds, unbounded queries -- the throughput path.  One workgroup
+//                    per 8^3-cell block stages the 10^3-cell region around it in LDS and ranks it with a DPP quad per
+//                    target: fp32 bound -> queue -> exact fp64 re-rank.  What ring 1 cannot settle goes to a todo list.
+//   knn_kernel       (first half) everything else: fp64 clouds, radius-bounded multi-GPU queries, the todo list.
+//                    8 lanes per target, 8 targets per wave64, 32 per 256-thread workgroup:
 //   - ring 1 (the 3x3x3 cells around the target) is 9 x-rows of 3 cells.  The group's lanes look the rows'
 //     cell ranges up in parallel (one latency for all of them), then the rows are processed centre first;
 //     a row's surviving cells are flattened into one index space so that the 8 lanes always read 8 consecutive
@@ -16,12 +21,12 @@
 //     row's batch is already in flight while the current one is ranked;
 //   - the running top-k lives in registers, distributed over the group's lanes (lane L holds ranks
 //     [L*KPL, (L+1)*KPL), KPL = ceil(k/8)), ordered by the total order (d2, original index);
-//   - a candidate is offered with one group ballot; an insertion is a one-position shift across lanes done
-//     with DPP row operations (no LDS traffic);
+//   - a candidate is offered with one group ballot, accepted through one ballot bit of the lane that holds rank
+//     k-1, and inserted as a one-position shift across lanes done with DPP row operations (no LDS traffic);
 //   - rings >= 2 (needed by the few targets whose k-th neighbour is farther than one cell) use a plain
 //     row-by-row walk.
-// Control flow is uniform inside a group (all 8 lanes take every branch together), so cross-lane operations
-// never see an inactive partner; different groups of a wave diverge freely.
+// Control flow is uniform inside a group (all lanes of a group / quad take every branch together), so cross-lane
+// operations never see an inactive partner; different groups of a wave diverge freely.
 #include "pt_internal.h"
 
 namespace {
