@@ -24,11 +24,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (N source, M target, k, seed)  -- SURVEY.md 8(d)
+    # name: (N source, M target, k, seed)  -- SURVEY.md 8(d); C5 is clustered + fp16 (see WORKLOAD_KIND)
+    "C1": (10_000, 1_000, 1, 0xC1),
     "C2": (10_000_000, 1_000_000, 8, 0xC2),
     "C3": (100_000_000, 10_000_000, 16, 0xC3),
     "C4": (1_000_000_000, 50_000_000, 8, 0xC4),
+    "C5": (1_000_000_000, 50_000_000, 32, 0xC5),
 }
+WORKLOAD_KIND = {"C5": ("clustered", "f16")}      # everything else: uniform, fp32
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 KERNEL_NAMES = ["bbox_reduce", "pass1_histogram", "pass1_scatter", "pass2_histogram_scan", "pass2_scatter", "finalize_cellsort",
                 "target_sort", "knn_query"]
@@ -103,8 +106,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: ranks may share one GPU, collectives staged through host memory")
-    ap.add_argument("--n", type=int, default=0, help="override the workload's source count (rehearsals)")
-    ap.add_argument("--m", type=int, default=0, help="override the workload's target count (rehearsals)")
+    ap.add_argument("--source-points", dest="n", type=int, default=0, help="override the workload's source count (rehearsals)")
+    ap.add_argument("--target-points", dest="m", type=int, default=0, help="override the workload's target count (rehearsals)")
     args = ap.parse_args()
 
     import torch
@@ -144,12 +147,24 @@ def main():
     axis = 0
     bounds = sharding.uniform_slab_bounds(world)
     pt = pkg.PointsTransfer(device=local_rank, k_hint=k)
+    dist_name, type_name = WORKLOAD_KIND.get(args.workload, ("uniform", "f32"))
+    gen = dict(dist=pkg.capi.DIST_CLUSTERED if dist_name == "clustered" else pkg.capi.DIST_UNIFORM,
+               xyz_type=pkg.F16 if type_name == "f16" else pkg.F32)
+    if dist_name == "clustered" and world > 1:
+        # equal-count slabs of a non-uniform cloud: quantiles of a sample of the generator's own output.  The generator is
+        # index-addressable and i.i.d., so every rank derives the same bounds from the same small prefix: no communication.
+        with pkg.PointsTransfer(device=local_rank) as probe:
+            probe.build_synth(4_000_000, seed, **gen)
+            probe.targets_synth(1_000_000, seed, **gen)
+            sx = torch.empty((3, probe.num_targets), dtype=torch.float32, device=dev)
+            probe.resident_target_xyz_dev(sx)
+            bounds = sharding.quantile_slab_bounds(sx[axis], world)
     if world > 1:
-        pt.build_synth(n_total, seed, slab_axis=axis, slab_lo=bounds[rank], slab_hi=bounds[rank + 1])
-        pt.targets_synth(m_total, seed, slab_axis=axis, slab_lo=bounds[rank], slab_hi=bounds[rank + 1])
+        pt.build_synth(n_total, seed, slab_axis=axis, slab_lo=bounds[rank], slab_hi=bounds[rank + 1], **gen)
+        pt.targets_synth(m_total, seed, slab_axis=axis, slab_lo=bounds[rank], slab_hi=bounds[rank + 1], **gen)
     else:
-        pt.build_synth(n_total, seed)
-        pt.targets_synth(m_total, seed)
+        pt.build_synth(n_total, seed, **gen)
+        pt.targets_synth(m_total, seed, **gen)
     n_loc, m_loc = pt.num_source, pt.num_targets
     idx = torch.empty((m_loc, k), dtype=torch.int32, device=dev)
     d2 = torch.empty((m_loc, k), dtype=torch.float64, device=dev)
@@ -216,8 +231,8 @@ def main():
             "value": value, "unit": "target points/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %d-point source / %d targets / k=%d, uniform fp32 xyz in the unit cube, generator seed 0x%X"
-                                   % (args.workload, n_total, m_total, k, seed),
+            "config": {"workload": "%s: %d-point source / %d targets / k=%d, %s %s xyz in the unit cube, generator seed 0x%X"
+                                   % (args.workload, n_total, m_total, k, dist_name, type_name, seed),
                        "step": "grid build + target binning + k-NN + slab exchange/merge + mean blend%s, inputs resident in HBM"
                                % (" + PCA normals" if with_pca else ""),
                        "parallelism": "slab%d" % world if world > 1 else "single", "backend": args.backend if world > 1 else None},
