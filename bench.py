@@ -86,6 +86,9 @@ def cpu_baseline(n_total, m_total, k, seed):
     t1 = time.perf_counter()
     kd.query(tgt, k)                         # OpenMP over targets, all host cores
     t2 = time.perf_counter()
+    m1 = max(1000, ms // 40)
+    kd.query(tgt[:, :m1], k, nthreads=1)     # the reference's default build is single-threaded (src/CMakeLists.txt:26)
+    t3 = time.perf_counter()
     kd.close()
     cores = O.num_threads()
     return {
@@ -94,6 +97,7 @@ def cpu_baseline(n_total, m_total, k, seed):
                   "kd-tree build %.2f s on 1 thread + query %.3f s on %d threads; value = sample targets / (build + query)"
                   % (ns, n_total, ms, m_total, k, t1 - t0, t2 - t1, cores),
         "query_only_value": ms / (t2 - t1),
+        "query_only_1thread_value": m1 / (t3 - t2),
     }
 
 

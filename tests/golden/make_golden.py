@@ -56,6 +56,13 @@ def main():
         c, n = O.blend(store["c1_k8_idx"], store["c1_k8_d2"], rgb, nrm, mode)
         store["c1_k8_blend%d_rgb" % mode] = c
         store["c1_k8_blend%d_nrm" % mode] = n
+    # PCA normals (build-defined) for c1 / k=16 (first 256 targets)
+    pn, plan = O.pca_normals(store["c1_k16_idx"], src, nrm)
+    store["c1_k16_pca_nrm"] = pn
+    store["c1_k16_pca_planarity"] = plan
+    # clustered generator KATs (seed 0xC5): first 8 sources / targets of a 1000 / 100 set
+    store["kat_clustered_src"] = O.synth_xyz(0xC5, 0, 8, dist=1)
+    store["kat_clustered_tgt"] = O.synth_xyz(0xC5, 1, 8, dist=1, n_total=1000, m_total=100)
     # generator KATs: first 8 values of each stream for seed 0xC1
     store["kat_src_xyz"] = O.synth_xyz(0xC1, 0, 8)
     store["kat_tgt_xyz"] = O.synth_xyz(0xC1, 1, 8)

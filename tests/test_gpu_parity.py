@@ -307,6 +307,14 @@ def test_blend_modes_match_golden(pt, oracle, golden, golden_cases):
     assert np.abs(c - rc).max() / 255 <= TOL and np.abs(n - rn).max() <= TOL
 
 
+def test_pca_matches_golden(pt, oracle, golden, golden_cases):
+    src, tgt = golden_cases["c1"]
+    pt.build(src, oracle.synth_rgb(0xC1, 10000), oracle.synth_nrm(0xC1, 10000))
+    got = pt.pca_normals(golden["c1_k16_idx"])
+    ok = golden["c1_k16_pca_planarity"] < 0.2          # uniform volume data: most neighbourhoods are NOT planar; compare the well-conditioned ones
+    assert ok.any() and np.abs(got[ok] - golden["c1_k16_pca_nrm"][ok]).max() <= 1e-4
+
+
 def test_pca_normals(pt, oracle):
     rng = np.random.default_rng(5)
     n = 50000

@@ -20,6 +20,11 @@ def test_generator_kats(oracle, golden):
     assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-6)
 
 
+def test_clustered_generator_kats(oracle, golden):
+    assert np.array_equal(oracle.synth_xyz(0xC5, 0, 8, dist=1), golden["kat_clustered_src"])
+    assert np.array_equal(oracle.synth_xyz(0xC5, 1, 8, dist=1, n_total=1000, m_total=100), golden["kat_clustered_tgt"])
+
+
 def test_clustered_generator_shape(oracle):
     n, m = 50000, 2500
     src = oracle.synth_xyz(0xC5, 0, n, dist=1)
@@ -126,6 +131,8 @@ def test_oracle_blend_and_pca(oracle, golden, golden_cases):
         assert np.array_equal(c, golden["c1_k8_blend%d_rgb" % mode]) and np.array_equal(n, golden["c1_k8_blend%d_nrm" % mode])
     c, n = oracle.blend(idx, d2, rgb, nrm, 0)
     assert np.allclose(c, rgb[idx].astype(np.float64).mean(axis=1), atol=1e-4)
+    pn, plan = oracle.pca_normals(golden["c1_k16_idx"], src, nrm)
+    assert np.allclose(pn, golden["c1_k16_pca_nrm"], atol=1e-6) and np.allclose(plan, golden["c1_k16_pca_planarity"], atol=1e-9)
     # PCA: points on the plane z = 0.3 + 0.1x must give normal ~ (-0.1, 0, 1)/|.|
     rng = np.random.default_rng(5)
     p = rng.random((3, 2000)); p[2] = 0.3 + 0.1 * p[0]
