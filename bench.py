@@ -81,6 +81,7 @@ def cpu_baseline(n_total, m_total, k, seed):
     ms = max(1000, min(m_total, ns // ratio))
     src = O.synth_xyz(seed, 0, ns)
     tgt = O.synth_xyz(seed, 1, ms)
+    cores = O.num_threads()                  # before the 1-thread run below pins OpenMP to one thread
     t0 = time.perf_counter()
     kd = O.KdTree(src)                       # single-threaded, like the reference's CGAL build
     t1 = time.perf_counter()
@@ -90,7 +91,6 @@ def cpu_baseline(n_total, m_total, k, seed):
     kd.query(tgt[:, :m1], k, nthreads=1)     # the reference's default build is single-threaded (src/CMakeLists.txt:26)
     t3 = time.perf_counter()
     kd.close()
-    cores = O.num_threads()
     return {
         "value": ms / (t2 - t0), "unit": "target points/sec", "cores": cores, "kind": "port",
         "sample": "first %d of %d source points and first %d of %d targets (same N/M ratio, same generator/seed), k=%d; "
