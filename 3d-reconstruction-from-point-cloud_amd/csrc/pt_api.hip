@@ -38,6 +38,7 @@ struct pt_ctx {
   double rho = 4.0;            // points per cell: 10^3-cell regions of ~4000 records let TWO tile workgroups share a CU
                                // (k-NN at C4: rho 8 -> 39.8 ms, 6 -> 32.4 ms, 4 with the small geometry -> 23.2 ms)
   int sync = 1;
+  int adaptive = 1;            // refine the cell size when the occupied cells hold far more than rho points (non-uniform clouds)
   int tile = 1;                // 1: tile kernel + group kernel for leftovers (fp32, unbounded); 0: group kernel only
   size_t dev_bytes = 0;
 
@@ -136,12 +137,13 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
   tb.scan_tmp = p; p += (size_t)nblocks / 2048 + 16;
   tb.chunk_hist = p; p += (nchunks + 1) * nbins1;
   tb.chunk_gsum = p;
+  tb.occupied = nullptr;
   tb.ev = nullptr;
   return PT_OK;
 }
 
 // choose the grid from the bounding box: cubic cells of side h with about rho points each
-void choose_grid(pt_ctx* c, const double mn[3], const double mx[3]) {
+void choose_grid(pt_ctx* c, const double mn[3], const double mx[3], double force_h = 0.0) {
   GridParams& g = c->gp;
   double ext[3], maxext = 0.0;
   for (int a = 0; a < 3; ++a) { ext[a] = mx[a] - mn[a]; if (!(ext[a] >= 0)) ext[a] = 0; maxext = std::max(maxext, ext[a]); }
@@ -152,6 +154,7 @@ void choose_grid(pt_ctx* c, const double mn[3], const double mx[3]) {
     h = std::cbrt(vol * c->rho / (double)c->n);
     if (!(h > 0) || !std::isfinite(h)) h = maxext;
     h = std::max(h, maxext / 60000.0);     // <= ~2^16 cells per axis
+    if (force_h > 0) h = std::max(force_h, maxext / 60000.0);
   }
   for (;;) {
     const double inv_h = 1.0 / h;
@@ -193,15 +196,45 @@ int rebuild(pt_ctx* c) {
     for (int a = 0; a < 3; ++a)
       if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) return fail(c, PT_ERR_ARG, "source coordinates are not finite");
   }
-  choose_grid(c, mn, mx);
-  const uint32_t nblocks = (uint32_t)c->gp.nblocks;
-  const size_t ncells = (size_t)nblocks * PT_BLOCK_CELLS;
-  RES(c, c->cell_start, (ncells + 1) * sizeof(uint32_t));
-  RES(c, c->rec, std::max<size_t>(c->n, 1) * recsize(c->src_type));
-  RES(c, c->rec_tmp, std::max<size_t>(c->n, 1) * recsize(c->src_type));
-  { int r = make_tables(c, c->stb_mem, c->stb, nblocks, (uint32_t)c->n, recsize(c->src_type)); if (r != PT_OK) return r; }
-  c->stb.ev = c->sev;
-  if (c->src_type == PT_F32) run_source_sort<float, RecF>(c); else run_source_sort<double, RecD>(c);
+  // Grid choice.  The first guess assumes the cloud fills its bounding box; finalize counts the non-empty cells, and when
+  // those hold far more than rho points each (surfaces, clusters) the cell size is refined -- at most twice, and never
+  // beyond what the dense cell table allows (choose_grid coarsens again if the macro-block limit is hit).
+  double force_h = 0.0;
+  uint32_t nblocks = 0;
+  size_t ncells = 0;
+  c->st.n_refine = 0;
+  for (int iter = 0;; ++iter) {
+    choose_grid(c, mn, mx, force_h);
+    nblocks = (uint32_t)c->gp.nblocks;
+    ncells = (size_t)nblocks * PT_BLOCK_CELLS;
+    RES(c, c->cell_start, (ncells + 1) * sizeof(uint32_t));
+    RES(c, c->rec, std::max<size_t>(c->n, 1) * recsize(c->src_type));
+    RES(c, c->rec_tmp, std::max<size_t>(c->n, 1) * recsize(c->src_type));
+    { int r = make_tables(c, c->stb_mem, c->stb, nblocks, (uint32_t)c->n, recsize(c->src_type)); if (r != PT_OK) return r; }
+    c->stb.ev = c->sev;
+    uint32_t* occ = (uint32_t*)c->counter.p + 8;
+    c->stb.occupied = c->adaptive ? c->stb.block_count : nullptr;     // block_count is dead once block_start exists
+    if (c->src_type == PT_F32) run_source_sort<float, RecF>(c); else run_source_sort<double, RecD>(c);
+    c->st.rho_occupied = 0.0;
+    if (!c->adaptive || !c->n) break;
+    HIPCHK(c, hipMemsetAsync(occ, 0, 4, c->stream));
+    pt_launch_sum_u32(c->stb.block_count, nblocks, occ, c->stream);
+    HIPCHK(c, hipMemcpyAsync(c->h_counter + 8, occ, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double occupied = std::max<double>(1.0, c->h_counter[8]);
+    c->st.rho_occupied = (double)c->n / occupied;
+    if (iter >= 2 || c->st.rho_occupied <= 2.5 * c->rho) break;
+    const double h_old = c->gp.h;
+    const int d0 = c->gp.dim[0], d1 = c->gp.dim[1], d2 = c->gp.dim[2];
+    force_h = h_old * std::pow(c->rho * 1.25 / c->st.rho_occupied, 1.0 / 2.5);     // occupied cells grow ~ h^-2 .. h^-3
+    GridParams probe = c->gp;
+    choose_grid(c, mn, mx, force_h);
+    const bool changed = c->gp.dim[0] != d0 || c->gp.dim[1] != d1 || c->gp.dim[2] != d2;
+    const bool finer = c->gp.h < h_old * 0.95;
+    c->gp = probe;
+    if (!changed || !finer) break;                 // already at the resolution limit (or nothing left to split)
+    ++c->st.n_refine;
+  }
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   HIPCHK(c, hipGetLastError());
   c->built = true;
@@ -210,6 +243,7 @@ int rebuild(pt_ctx* c) {
   c->st.cell_size = c->gp.h;
   c->st.n_cells = ncells;
   c->st.n_levels = nblocks <= PT_MAXBINS ? 1 : 2;
+  (void)ncells;
   const uint64_t s = tsize(c->src_type) * 3;
   c->st.bytes_alg_build = c->n * (2 * s + 4);
   if (c->sync) {
@@ -389,6 +423,7 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
     return PT_OK;
   }
   if (!strcmp(name, "sync")) { c->sync = value != 0; return PT_OK; }
+  if (!strcmp(name, "adaptive")) { c->adaptive = value != 0; return PT_OK; }
   if (!strcmp(name, "tile")) { c->tile = (int)value; return PT_OK; }   // 0 group kernel only, 1 auto, 2 small tiles, 3 large tiles
   if (!strcmp(name, "own_stream")) { if (value != 0) c->stream = c->own_stream; return PT_OK; }
   return fail(c, PT_ERR_ARG, "unknown parameter '%s'", name);

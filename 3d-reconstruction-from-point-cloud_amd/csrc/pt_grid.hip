@@ -387,12 +387,13 @@ constexpr int FWG = 512;        // finalize workgroup: one thread per local cell
 constexpr int FITEMS = 12;      // records a thread keeps in registers: blocks up to 6144 points are read once
 template <class Rec>
 __global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ in, Rec* __restrict__ out, GridParams gp,
-                                                       const uint32_t* __restrict__ block_start, uint32_t* cell_start) {
+                                                       const uint32_t* __restrict__ block_start, uint32_t* cell_start, uint32_t* occupied) {
   __shared__ uint32_t cnt[PT_BLOCK_CELLS];
   __shared__ uint32_t wsum[FWG / 64];
   const uint32_t b = blockIdx.x;
   const uint32_t s = block_start[b], e = block_start[b + 1];
   if (s == e) {   // empty block: only the table
+    if (occupied && threadIdx.x == 0) occupied[b] = 0;
     if (cell_start) {
       cell_start[b * PT_BLOCK_CELLS + threadIdx.x] = s;
       if (b == gridDim.x - 1 && threadIdx.x == 0) cell_start[(b + 1) * PT_BLOCK_CELLS] = e;
@@ -427,12 +428,23 @@ __global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ i
   // exclusive scan of the 512 cell counts, one per thread
   const uint32_t c0 = cnt[threadIdx.x];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // non-empty cells of this block (the host derives the points per OCCUPIED cell from their sum).  One plain store per
+  // block into a table: a single shared atomic counter would serialise ~5e5 workgroups on one address.
+  const uint32_t nzw = (uint32_t)__popcll(__ballot(c0 > 0));
   const uint32_t incl = wave_incl_scan(c0);
+  __shared__ uint32_t wnz[FWG / 64];
   if (lane == 63) wsum[w] = incl;
+  if (lane == 0) wnz[w] = nzw;
   __syncthreads();
   uint32_t off = 0;
 #pragma unroll
   for (int i = 0; i < FWG / 64; ++i) if (i < w) off += wsum[i];
+  if (occupied && threadIdx.x == 0) {
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < FWG / 64; ++i) nz += wnz[i];
+    occupied[b] = nz;
+  }
   const uint32_t ex = off + incl - c0;
   cnt[threadIdx.x] = ex;                      // cursor, relative to s
   if (cell_start) {
@@ -454,6 +466,14 @@ __global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ i
       out[s + atomicAdd(&cnt[pt_local_cell(cx, cy, cz)], 1u)] = v;
     }
   }
+}
+
+__global__ __launch_bounds__(WG) void sum_u32_kernel(const uint32_t* __restrict__ v, uint32_t n, uint32_t* out) {
+  uint32_t acc = 0;
+  for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) acc += v[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
 
 template <class Rec> constexpr int items_for() { return sizeof(Rec) == 16 ? 8 : 4; }
@@ -532,7 +552,7 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
                          tb.tile_first1, 1, tb.cursor2);
     mark(4);
     blocked = tmp;
-    if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, blocked, out_final, gp, tb.block_start, cell_start);
+    if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, blocked, out_final, gp, tb.block_start, cell_start, tb.occupied);
     mark(5);
     return do_finalize ? out_final : tmp;
   }
@@ -570,7 +590,7 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
     hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS_S, SW>), dim3(ntiles2), dim3(SW), 0, s, rl, tmp, gp, b2, tb.start1, tb.tile_first2,
                        (int)nmacro, tb.cursor2);
   mark(4);
-  if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start);
+  if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start, tb.occupied);
   mark(5);
   return do_finalize ? out_final : tmp;
 }
@@ -578,3 +598,7 @@ template const RecF* pt_launch_grid_sort<float, RecF>(const GridParams&, const f
                                                       RecF*, uint32_t*, const SortTables&, bool, hipStream_t);
 template const RecD* pt_launch_grid_sort<double, RecD>(const GridParams&, const double*, const double*, const double*, const uint32_t*, uint32_t,
                                                        RecD*, RecD*, uint32_t*, const SortTables&, bool, hipStream_t);
+void pt_launch_sum_u32(const uint32_t* v, uint32_t n, uint32_t* out, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(sum_u32_kernel, dim3(std::min<uint32_t>((n + WG - 1) / WG, 64)), dim3(WG), 0, s, v, n, out);
+}

@@ -18,6 +18,7 @@ struct SortTables {
   uint32_t* scan_tmp;    // [>= nblocks/2048 + 2]
   uint32_t* chunk_hist;  // [nchunks][nbins1]   per-chunk pass-1 histograms, then per-chunk bin cursors
   uint32_t* chunk_gsum;  // [ceil(nchunks/64)][nbins1]
+  uint32_t* occupied;    // optional [nblocks]: non-empty cells of every block, written by finalize (may alias block_count)
   hipEvent_t* ev;        // optional [6]: start, after hist1, scatter1, hist2+scan, scatter2, finalize (null = no timing)
 };
 
@@ -34,6 +35,7 @@ double pt_bbox_decode(uint64_t enc);
 template <class T, class Rec>
 const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* z, const uint32_t* gidx, uint32_t n,
                                Rec* out_final, Rec* tmp, uint32_t* cell_start, const SortTables& tb, bool do_finalize, hipStream_t s);
+void pt_launch_sum_u32(const uint32_t* v, uint32_t n, uint32_t* out, hipStream_t s);   // *out += sum(v[0..n))
 int pt_sort_tile_points(size_t rec_size);
 int pt_sort_chunk_tiles(uint32_t n, size_t rec_size);
 uint32_t pt_sort_num_chunks(uint32_t n, size_t rec_size);

@@ -100,7 +100,7 @@ class PointsTransfer:
     def stats(self):
         s = capi.Stats()
         self._chk(self._L.pt_stats(self._h, C.byref(s)))
-        return {f[0]: (list(getattr(s, f[0])) if f[0] in ("grid_dim", "ms_kernel") else getattr(s, f[0])) for f in s._fields_ if f[0] != "_pad"}
+        return {f[0]: (list(getattr(s, f[0])) if f[0] in ("grid_dim", "ms_kernel") else getattr(s, f[0])) for f in s._fields_ if not f[0].startswith("_pad")}
 
     @property
     def num_source(self):

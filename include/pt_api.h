@@ -83,6 +83,8 @@ typedef struct pt_stats_t {
    * [4] pass-2 scatter, [5] finalize (cell sort), [6] target sort (all passes), [7] k-NN kernel */
   double ms_kernel[8];
   uint64_t n_leftover;      /* targets of the last query that the tile kernel handed to the group kernel */
+  double rho_occupied;      /* points per NON-EMPTY cell of the last build (0 when adaptive is off) */
+  int32_t n_refine, _pad2;  /* how many times the last build refined its cell size */
 } pt_stats_t;
 
 /* ---- context ------------------------------------------------------------------------ */
@@ -95,7 +97,8 @@ void pt_ctx_destroy(pt_ctx*);
 int  pt_set_stream(pt_ctx*, void* hip_stream);
 /* Tunables: "k_hint" (the k later queries will use: picks the cell density before a build; default 8), "rho" (points
  * per grid cell, set directly; default 4), "sync" (1 = every call blocks until
- * the GPU is done, default 1; 0 = _dev calls only enqueue), "tile" (0 = group kernel only, 1 = tile kernel +
+ * the GPU is done, default 1; 0 = _dev calls only enqueue), "adaptive" (1 = refine the cell
+ * size when non-empty cells hold far more than rho points, default; needs one host read-back per build), "tile" (0 = group kernel only, 1 = tile kernel +
  * group kernel for its leftovers with the geometry chosen from the cell density (default), 2 / 3 = force the small /
  * large tile geometry). */
 int  pt_set_param(pt_ctx*, const char* name, double value);
