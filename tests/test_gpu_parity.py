@@ -289,6 +289,31 @@ def test_clustered_distribution(pkg, oracle, xyz_type, k):
     assert 0.0 <= src.min() and src.max() <= 1.0          # (fp16 rounding can reach 1.0 exactly)
 
 
+def test_adaptive_cell_refinement(pkg, oracle):
+    """A surface-like cloud (what real scans are) fills few cells of a volume-sized grid: the build must notice and refine;
+    a uniform cloud must not be touched.  Results stay exact either way."""
+    rng = np.random.default_rng(33)
+    n = 400000
+    src = rng.random((3, n)).astype(np.float32)
+    src[2] = (0.5 + 0.2 * np.sin(3 * src[0]) * np.cos(2 * src[1]) + 1e-4 * rng.standard_normal(n)).astype(np.float32)   # a thin sheet
+    tgt = src[:, ::40] + (1e-3 * rng.standard_normal((3, n // 40))).astype(np.float32)
+    want = oracle.KdTree(src).query(tgt, 8)
+    for adaptive in (1, 0):
+        with pkg.PointsTransfer(device=0) as p:
+            p.set_param("adaptive", adaptive)
+            p.build(src)
+            st = p.stats()
+            _check_exact(p.query(tgt, 8), want, "sheet adaptive=%d" % adaptive)
+        if adaptive:
+            assert st["n_refine"] >= 1 and st["rho_occupied"] < 40, st
+        else:
+            assert st["n_refine"] == 0
+    with pkg.PointsTransfer(device=0) as p:
+        p.build(oracle.synth_xyz(3, 0, 300000))
+        st = p.stats()
+        assert st["n_refine"] == 0 and 3.5 < st["rho_occupied"] < 5.5, st
+
+
 # ---- blend and PCA -------------------------------------------------------------------------------------------
 def test_blend_modes_match_golden(pt, oracle, golden, golden_cases):
     src, tgt = golden_cases["c1"]
