@@ -356,7 +356,14 @@ int upload_xyz(pt_ctx* c, DevBuf& dst, const void* xyz, int& xyz_type, uint64_t 
 // copy caller targets into the transient buffer (resident targets are not touched)
 int load_transient(pt_ctx* c, const void* xyz, int& xyz_type, uint64_t m, int on_device) {
   { int r = check_n(c, m, "m"); if (r) return r; }
-  return upload_xyz(c, c->x_xyz, xyz, xyz_type, m, on_device);
+  { int r = upload_xyz(c, c->x_xyz, xyz, xyz_type, m, on_device); if (r) return r; }
+  if (xyz_type == PT_F32 && c->src_type == PT_F64) {     // fp32 / fp16 targets against a double cloud: widen (exact)
+    RES(c, c->misc, std::max<uint64_t>(m, 1) * 3 * sizeof(double));
+    pt_launch_float_to_double((const float*)c->x_xyz.p, (double*)c->misc.p, m * 3, c->stream);
+    std::swap(c->x_xyz, c->misc);
+    xyz_type = PT_F64;
+  }
+  return PT_OK;
 }
 
 }  // namespace

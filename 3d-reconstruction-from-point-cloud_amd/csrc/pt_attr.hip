@@ -243,6 +243,11 @@ __global__ __launch_bounds__(WG) void half_to_float_kernel(const __half* __restr
   if (i < count) out[i] = __half2float(in[i]);
 }
 
+__global__ __launch_bounds__(WG) void float_to_double_kernel(const float* __restrict__ in, double* __restrict__ out, uint64_t count) {
+  const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+  if (i < count) out[i] = (double)in[i];
+}
+
 __global__ __launch_bounds__(WG) void iota_kernel(uint32_t* p, uint32_t n) {
   const uint32_t i = blockIdx.x * WG + threadIdx.x;
   if (i < n) p[i] = i;
@@ -298,4 +303,8 @@ void pt_launch_iota(uint32_t* p, uint32_t n, hipStream_t s) {
 void pt_launch_half_to_float(const void* in_half, float* out, uint64_t count, hipStream_t s) {
   if (!count) return;
   hipLaunchKernelGGL(half_to_float_kernel, dim3((uint32_t)((count + WG - 1) / WG)), dim3(WG), 0, s, (const __half*)in_half, out, count);
+}
+void pt_launch_float_to_double(const float* in, double* out, uint64_t count, hipStream_t s) {
+  if (!count) return;
+  hipLaunchKernelGGL(float_to_double_kernel, dim3((uint32_t)((count + WG - 1) / WG)), dim3(WG), 0, s, in, out, count);
 }

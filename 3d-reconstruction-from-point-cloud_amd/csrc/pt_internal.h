@@ -66,6 +66,7 @@ void pt_launch_synth_xyz(uint64_t seed, uint64_t stream, uint32_t n_total, int a
                          uint32_t* gidx, uint32_t* counter, uint32_t capacity, int round_f16, int dist, uint64_t src_total,
                          uint64_t tgt_total, hipStream_t s);
 void pt_launch_half_to_float(const void* in_half, float* out, uint64_t count, hipStream_t s);
+void pt_launch_float_to_double(const float* in, double* out, uint64_t count, hipStream_t s);
 void pt_launch_synth_attr(uint64_t seed, uint32_t n_total, Attr* attr, hipStream_t s);
 // reference AoS records (80-B stride, device copy) -> planar f64 xyz + attribute table
 void pt_launch_aos_split(const void* aos, uint32_t n, double* x, double* y, double* z, Attr* attr, hipStream_t s);

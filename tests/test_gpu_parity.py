@@ -175,7 +175,7 @@ def test_k_bounds_and_call_order(pkg, pt):
             pt.query(np.zeros((3, 1), np.float32), bad)
         assert e.value.code == pkg.capi.ERR_ARG
     with pytest.raises(pkg.PtError):
-        pt.query(np.zeros((3, 1), np.float64), 4)          # f64 targets against an f32 cloud
+        pt.query(np.zeros((3, 1), np.float64), 4)          # f64 targets against an f32 cloud would need narrowing: refused
 
 
 # ---- the reference's own record type: AoS Point, double coordinates ------------------------------------------
@@ -198,6 +198,9 @@ def test_aos_point_records_double_path(pkg, pt, oracle):
     # planar f64 entry point gives the same
     pt.build(cloud["ver"].T.copy(), xyz_type=pkg.F64)
     _check_exact(pt.query(verts["ver"].T.copy(), k, xyz_type=pkg.F64), want, "planar f64")
+    # fp32 targets against the double cloud are widened exactly
+    t32 = verts["ver"].T.astype(np.float32)
+    _check_exact(pt.query(t32, k), oracle.knn_bruteforce(cloud["ver"].T, t32.astype(np.float64), k), "f32 targets on f64 cloud")
 
 
 def test_fp16_coordinates(pkg, pt, oracle):
