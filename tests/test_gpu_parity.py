@@ -450,3 +450,58 @@ def test_full_size_c2_properties(pkg, oracle):
     wi, wd = oracle.KdTree(src).query(tgt[:, sel], k)
     assert np.array_equal(I[sel], wi) and np.array_equal(D[sel], wd)
     assert st["n_source"] == n and st["n_target"] == m and st["ms_query"] > 0
+
+
+def test_full_size_c3_sampled_exactness(pkg, oracle):
+    """BASELINE config 3 at full size (100M / 10M / k=16): valid, ascending, tie-broken, and exact on a sample against the
+    CPU kd-tree restatement built over the whole cloud."""
+    import torch
+    n, m, k, seed = 100_000_000, 10_000_000, 16, 0xC3
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.build_synth(n, seed)
+        p.targets_synth(m, seed)
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        p.query_resident_dev(k, idx, d2)
+        torch.cuda.synchronize()
+        assert bool((d2[:, 1:] >= d2[:, :-1]).all())
+        sel = torch.from_numpy(np.random.default_rng(1).choice(m, 5000, replace=False)).cuda()
+        I = idx[sel].cpu().numpy().view(np.uint32); D = d2[sel].cpu().numpy()
+    src = oracle.synth_xyz(seed, 0, n)
+    tgt = oracle.synth_xyz(seed, 1, m)[:, sel.cpu().numpy()]
+    wi, wd = oracle.KdTree(src).query(tgt, k)
+    assert np.array_equal(I, wi) and np.array_equal(D, wd)
+
+
+def test_full_size_c4_two_kernels_agree(pkg):
+    """BASELINE config 4 at full size (1B / 50M / k=8) is beyond what the CPU oracle can hold, so the check is structural:
+    results are valid / ascending / duplicate-free, a rebuild reproduces them bit for bit, and on a 200k-target sample the
+    tile kernel and the independent group kernel return identical neighbours and distances."""
+    import torch
+    n, m, k, seed = 1_000_000_000, 50_000_000, 8, 0xC4
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.build_synth(n, seed)
+        p.targets_synth(m, seed)
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        p.query_resident_dev(k, idx, d2)
+        torch.cuda.synchronize()
+        assert p.stats()["n_leftover"] < 0.01 * m
+        assert bool((d2[:, 1:] >= d2[:, :-1]).all()) and bool((idx.view(torch.int32) != -1).all())
+        srt = idx.to(torch.int64).sort(dim=1).values
+        assert bool((srt[:, 1:] != srt[:, :-1]).all())                       # no neighbour twice
+        chk = (idx.to(torch.int64) & 0xFFFFFFFF).sum().item(), d2.sum().item()
+        p.rebuild()
+        i2 = torch.empty_like(idx); e2 = torch.empty_like(d2)
+        p.query_resident_dev(k, i2, e2)
+        torch.cuda.synchronize()
+        assert ((i2.to(torch.int64) & 0xFFFFFFFF).sum().item(), e2.sum().item()) == chk and torch.equal(i2, idx)
+        del i2, e2, srt
+        xyz = torch.empty((3, m), dtype=torch.float32, device="cuda")
+        p.resident_target_xyz_dev(xyz)
+        sel = torch.randperm(m, device="cuda")[:200_000]
+        sx = xyz[:, sel].contiguous()
+        p.set_param("tile", 0)                                               # group kernel only
+        gi = torch.empty((200_000, k), dtype=torch.int32, device="cuda"); gd = torch.empty((200_000, k), dtype=torch.float64, device="cuda")
+        p.query_dev(sx, pkg.F32, 200_000, k, gi, gd)
+        torch.cuda.synchronize()
+        assert p.stats()["n_leftover"] == 0
+        assert torch.equal(gi, idx[sel]) and torch.equal(gd, d2[sel])
