@@ -292,9 +292,9 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     const RecF* tsorted = pt_launch_grid_sort<float, RecF>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecF*)c->trec.p, (RecF*)c->trec_tmp.p, nullptr, c->ttb, false, c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (c->tile && !bound2_dev && m && k <= 24) {     // beyond k = 24 a region that holds ring 1 no longer fits LDS
-      // regions (10^3 cells) that fit 4480 records with headroom run the two-workgroups-per-CU geometry
+      // regions (10^3 cells) that fit the small capacity with headroom run the two-workgroups-per-CU geometry
       const double cells = (double)c->gp.dim[0] * c->gp.dim[1] * c->gp.dim[2];
-      const int tile_small = c->tile == 2 || (c->tile == 1 && (double)c->n / cells * 1000.0 * 1.05 <= (k <= 8 ? 4480.0 : (k <= 16 ? 4224.0 : 3968.0)));
+      const int tile_small = c->tile == 2 || (c->tile == 1 && (double)c->n / cells * 1000.0 * 1.05 <= (double)(k <= 8 ? PT_TILE_CAP_SMALL_8 : PT_TILE_CAP_SMALL_16));
       uint32_t* todo_n = (uint32_t*)c->counter.p + 4;
       HIPCHK(c, hipMemsetAsync(todo_n, 0, 4, c->stream));
       pt_launch_knn_tile(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, c->ttb.block_start, k, idx_dev, d2_dev,

@@ -387,9 +387,10 @@ __global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __res
 // only (the fp32 pre-filter needs exact fp32 inputs).
 constexpr int TILE_R = 10, TILE_CELLS = TILE_R * TILE_R * TILE_R;
 // Two geometries: LARGE = 768 threads, 8448 staged records (132 KB, one workgroup per CU) for rho ~ 6-8;
-//                 SMALL = 512 threads, 4480 staged records ( 70 KB, two workgroups per CU: one stages while the other ranks).
-// queue entries per quad: room for the k survivors plus near-ties (LDS-limited at K = 32)
-template <int K> struct TileQ { static constexpr int CAP = K == 8 ? 16 : (K == 16 ? 32 : 48); };
+//                 SMALL = 512 threads, ~4460 staged records (70 KB, two workgroups per CU: one stages while the other ranks).
+// queue entries per quad (CAP: room for the k survivors plus whatever else the fp32 bound lets through) and per lane
+// (LCAP: every lane of the quad appends to its own segment, so no atomics and no counters in LDS)
+template <int K> struct TileQ { static constexpr int CAP = K == 8 ? 24 : (K == 16 ? 40 : 48), LCAP = K == 8 ? 8 : 16; };
 
 __device__ inline float dist2_f32(float qx, float qy, float qz, const RecF& r) {
   const float dx = qx - r.x, dy = qy - r.y, dz = qz - r.z;
@@ -432,6 +433,11 @@ __device__ inline void quad_merge_sorted(float (&l)[K]) {
   for (int j = 0; j < K; ++j) l[j] = c[j];
 }
 
+// one LDS-DMA wave-instruction: active lane L copies 16 bytes from its own `g` to `lbase + L` (lbase wave-uniform)
+__device__ inline void glds16(const uint4* g, uint4* lbase) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lbase, 16, 0, 0);
+}
+
 template <int K, int TILE_CAP, int TWG>
 __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(GridParams gp, const RecF* __restrict__ src, const uint32_t* __restrict__ cs,
                                                         const RecF* __restrict__ tgt, const uint32_t* __restrict__ tblock_start, int k,
@@ -439,14 +445,15 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
                                                         uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_n) {
   constexpr int NW = TWG / 64;
   constexpr int TILE_QUADS = TWG / 4;
-  constexpr int TILE_QCAP = TileQ<K>::CAP;
+  constexpr int TILE_QCAP = TileQ<K>::CAP, TILE_LCAP = TileQ<K>::LCAP;
   __shared__ __attribute__((aligned(16))) RecF lrec[TILE_CAP];
-  __shared__ uint32_t lstart[TILE_CELLS + 8];
-  __shared__ __attribute__((aligned(16))) uint16_t queue[TILE_QUADS * TILE_QCAP];   // doubles as gstart[] during staging
-  __shared__ uint32_t qn[TILE_QUADS];
+  __shared__ uint16_t lstart[TILE_CELLS + 8];
+  __shared__ __attribute__((aligned(16))) uint16_t queue[TWG * TILE_LCAP];          // doubles as gstart[] during staging
   __shared__ uint32_t wsum[NW];
+  __shared__ uint32_t ptotal;
   uint32_t* gstart = reinterpret_cast<uint32_t*>(queue);
   static_assert(sizeof(queue) >= TILE_CELLS * sizeof(uint32_t), "gstart aliases the queue");
+  static_assert(TILE_CAP < 65536, "LDS offsets are 16-bit");
 
   const uint32_t b = blockIdx.x;
   const uint32_t ts = tblock_start[b], te = tblock_start[b + 1];
@@ -488,14 +495,13 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = threadIdx.x * 4 + i;
-      if (c < TILE_CELLS) lstart[c] = ex;
+      if (c < TILE_CELLS) lstart[c] = (uint16_t)(ex < 65535u ? ex : 65535u);
       ex += cnt[i];
     }
-    if (threadIdx.x == 0) lstart[TILE_CELLS] = tot;
-    if (threadIdx.x < TILE_QUADS) qn[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { lstart[TILE_CELLS] = (uint16_t)(tot < 65535u ? tot : 65535u); ptotal = tot; }
   }
   __syncthreads();
-  const uint32_t P = lstart[TILE_CELLS];
+  const uint32_t P = ptotal;
   if (P > (uint32_t)TILE_CAP) {                     // denser than the LDS budget: the group kernel takes the whole tile
     for (uint32_t t = ts + threadIdx.x; t < te; t += TWG) todo[atomicAdd(todo_n, 1u)] = t;
     return;
@@ -510,30 +516,18 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int NROWS = TILE_R * TILE_R;
     constexpr int RPW = (NROWS + NW - 1) / NW;                      // rows per wave (9 or 13)
-    constexpr int RB = TILE_CAP > 5000 ? RPW : (RPW + 1) / 2;       // rows per batch: bounded by the VGPR budget of the geometry
     bool long_rows = false;
+    // rows go HBM -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, per-lane source address),
+    // no staging registers: every row of the wave and the halo loads below are in flight together -- ONE exposed latency.
 #pragma unroll
-    for (int b0 = 0; b0 < RPW; b0 += RB) {
-      uint4 t0[RB], t1[RB];
-      uint32_t la[RB], len[RB];
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const int rr = w + (b0 + i) * NW;
-        const bool ok = (b0 + i < RPW) && rr < NROWS;
-        const int row = ok ? rr : NROWS - 1;
-        const int c1 = row * TILE_R + 1;
-        la[i] = lstart[c1];
-        len[i] = ok ? lstart[c1 + 8] - la[i] : 0u;
-        const uint32_t ga = gstart[c1];
-        t0[i] = make_uint4(0, 0, 0, 0); t1[i] = make_uint4(0, 0, 0, 0);
-        if ((uint32_t)lane < len[i]) t0[i] = src4[ga + lane];
-        if ((uint32_t)lane + 64u < len[i]) t1[i] = src4[ga + lane + 64u];
-        long_rows |= len[i] > 128u;
-      }
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        if ((uint32_t)lane < len[i]) l4[la[i] + lane] = t0[i];
-        if ((uint32_t)lane + 64u < len[i]) l4[la[i] + lane + 64u] = t1[i];
+    for (int i = 0; i < RPW; ++i) {
+      const int rr = w + i * NW;
+      if (rr < NROWS) {                                             // wave-uniform
+        const int c1 = rr * TILE_R + 1;
+        const uint32_t la = lstart[c1], len = lstart[c1 + 8] - la, ga = gstart[c1];
+        if ((uint32_t)lane < len) glds16(src4 + ga + lane, l4 + la);
+        if ((uint32_t)lane + 64u < len) glds16(src4 + ga + lane + 64u, l4 + la + 64u);
+        long_rows |= len > 128u;
       }
     }
     const int g8 = threadIdx.x >> 3, l8 = threadIdx.x & 7;
@@ -599,20 +593,17 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
       cc[a] = (int)fmin(fmax(u[a], 0.0), (double)(gp.dim[a] - 1));
     }
     const int rx = active ? cc[0] - ox : 1, ry = active ? cc[1] - oy : 1, rz = active ? cc[2] - oz : 1;   // in [1, 8]
-    // this lane's share of ring 1: rows ql and ql+4 (3 cells each) and, for lanes 1..3, cell ql-1 of row 8
-    const int rowA = ql, rowB = ql + 4;
-    const int cA = ((rz + row_dz(rowA)) * TILE_R + (ry + row_dy(rowA))) * TILE_R + (rx - 1);
-    const int cB = ((rz + row_dz(rowB)) * TILE_R + (ry + row_dy(rowB))) * TILE_R + (rx - 1);
-    const int cC = ((rz + row_dz(8)) * TILE_R + (ry + row_dy(8))) * TILE_R + (rx - 1) + (ql > 0 ? ql - 1 : 0);
-    uint32_t sA[4], sB[4], sC[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { sA[j] = lstart[cA + j]; sB[j] = lstart[cB + j]; }
-    sC[0] = lstart[cC]; sC[1] = (ql > 0) ? lstart[cC + 1] : sC[0];
+    const int cbase = (rz * TILE_R + ry) * TILE_R + (rx - 1);          // region cell left of the target's cell
+    // The four lanes of a quad walk every run of records together, lane ql taking records ql, ql+4, ... of it: the quad
+    // reads 64 contiguous bytes per step, every lane sees a quarter of every cell (even shares), and the trip counts are
+    // the same for the whole quad.
 
-    // ---- pass 1: the K smallest fp32 distances of my share (values only).  (Shorter per-lane lists would still give a
-    //      valid bound, but the centre row's lane usually holds most of the k nearest: measured 3.7 % of the targets
-    //      overflow the queue with 3K/4, 17 % with K/2, 7e-7 with K.) ----
-    constexpr int M = K;
+    // ---- pass 1: the K smallest fp32 distances (values only) of the 2x2x2 cells nearest to the target -- on each axis
+    //      the target's cell and its neighbour on the target's side.  Any candidate set with >= k members gives a valid
+    //      bound; this one holds most of the k nearest at a quarter of ring 1's reads.  (Fewer than k points there: the
+    //      bound is +inf, the queue overflows and the target goes to the todo list.)  Per-lane lists shorter than K would
+    //      still be valid but loosen the bound: measured 3.7 % of the targets overflow the queue with 3K/4, 17 % with K/2. ----
+    const int sx = (u[0] - (double)cc[0]) >= 0.5 ? 0 : -1, sy = (u[1] - (double)cc[1]) >= 0.5 ? 0 : -1, sz = (u[2] - (double)cc[2]) >= 0.5 ? 0 : -1;
     float l32[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) l32[j] = INFINITY;
@@ -620,22 +611,20 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
       float prev = l32[0];
       l32[0] = fminf(x, prev);
 #pragma unroll
-      for (int j = 1; j < M; ++j) { const float cur = l32[j]; l32[j] = __builtin_amdgcn_fmed3f(x, prev, cur); prev = cur; }
+      for (int j = 1; j < K; ++j) { const float cur = l32[j]; l32[j] = __builtin_amdgcn_fmed3f(x, prev, cur); prev = cur; }
     };
-    auto scan1 = [&](uint32_t p, uint32_t pe) {
-      for (; p + 4 <= pe; p += 4) {                    // 4 LDS reads in flight per lane
-        float x[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p + i]));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) push1(x[i]);
+    for (int o = 0; o < 4; ++o) {
+      const int c = cbase + ((sz + (o >> 1)) * TILE_R + (sy + (o & 1))) * TILE_R + 1 + sx;
+      const uint32_t e = lstart[c + 2];
+      uint32_t p = lstart[c] + ql;
+      if (active) {
+        for (; p + 4 < e; p += 8) {                    // two LDS reads in flight per lane
+          const float x0 = dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p])), x1 = dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p + 4]));
+          push1(x0); push1(x1);
+        }
+        if (p < e) push1(dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p])));
       }
-      for (; p < pe; ++p) push1(dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p])));
-    };
-    if (active) {
-      scan1(sA[0], sA[3]);
-      scan1(sB[0], sB[3]);
-      scan1(sC[0], sC[1]);
     }
     // the quad's K smallest: two bitonic merges through DPP (all lanes of the wave take part: no divergence here)
     quad_merge_sorted<K, DPP_QP_1032>(l32);
@@ -644,71 +633,70 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
 #pragma unroll
     for (int j = 1; j < K; ++j) kv = (j == k - 1) ? l32[j] : kv;
     const float thr = kth_bound32(kv);
-    const double lim = (double)thr;
 #if defined(PT_ABLATE) && PT_ABLATE == 2
     if (thr >= 0.f) continue;                       // timing-only build: staging + pass 1 (results are garbage)
 #endif
 
-    // ---- pass 2: re-scan under the bound, queue what is within it ----
-    auto gap = [&](int a, int lo, int hi) -> double {
-      const double g = fmax((double)lo - u[a], u[a] - (double)(hi + 1)) - PT_CELL_EPS;
-      return fmax(g, 0.0);
+    // ---- pass 2: scan ring 1 under the bound; what is within it goes to this lane's own queue segment.  Rows and their end
+    //      cells are pruned in fp32 on the target's position inside its cell, with gaps UNDER-estimated by a slack far above
+    //      the rounding of the products, so nothing that could hold a candidate within the bound is skipped. ----
+    const float fx = (float)(u[0] - (double)cc[0]), fy = (float)(u[1] - (double)cc[1]), fz = (float)(u[2] - (double)cc[2]);
+    const float h2f = (float)h2;
+    auto gapf = [&](float f, int d) -> float {         // distance (in cells) from offset f in the centre cell to cell d = -1, 0, +1
+      const float g = fmaxf((float)d - f, f - (float)(d + 1)) - 4e-6f * (1.f + fabsf(f));
+      return fmaxf(g, 0.f);
     };
-    bool overflow = false;
+    const float g2x[3] = {gapf(fx, -1) * gapf(fx, -1), 0.f, gapf(fx, 1) * gapf(fx, 1)};
+    const float g2y[3] = {gapf(fy, -1) * gapf(fy, -1), gapf(fy, 0) * gapf(fy, 0), gapf(fy, 1) * gapf(fy, 1)};
+    const float g2z[3] = {gapf(fz, -1) * gapf(fz, -1), gapf(fz, 0) * gapf(fz, 0), gapf(fz, 1) * gapf(fz, 1)};
+    uint16_t* myq = &queue[threadIdx.x * TILE_LCAP];
+    uint32_t nmine = 0;
     auto push2 = [&](float x, uint32_t p) {
       if (x <= thr) {
-        const uint32_t pos = atomicAdd(&qn[quad], 1u);
-        if (pos < (uint32_t)TILE_QCAP) queue[quad * TILE_QCAP + pos] = (uint16_t)p; else overflow = true;
+        if (nmine < (uint32_t)TILE_LCAP) myq[nmine] = (uint16_t)p;
+        ++nmine;
       }
     };
-    auto scan2 = [&](uint32_t p, uint32_t pe) {
-      for (; p + 4 <= pe; p += 4) {
-        float x[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p + i]));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) push2(x[i], p + i);
+    for (int r = 0; r < 9; ++r) {
+      const int dy = r % 3 - 1, dz = r / 3 - 1;
+      const int c = cbase + (dz * TILE_R + dy) * TILE_R;
+      const float s2 = g2y[dy + 1] + g2z[dz + 1];
+      const bool row_on = active && !(s2 * h2f > thr);
+      const bool lo_on = !((g2x[0] + s2) * h2f > thr), hi_on = !((g2x[2] + s2) * h2f > thr);
+      const uint32_t e = row_on ? (uint32_t)lstart[hi_on ? c + 3 : c + 2] : 0u;
+      uint32_t p = (uint32_t)lstart[lo_on ? c : c + 1] + ql;
+      for (; p + 4 < e; p += 8) {
+        const float x0 = dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p])), x1 = dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p + 4]));
+        push2(x0, p); push2(x1, p + 4);
       }
-      for (; p < pe; ++p) push2(dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p])), p);
-    };
-    auto scan2_row = [&](int r, const uint32_t (&s4)[4]) {
-      const int y = cc[1] + row_dy(r), z = cc[2] + row_dz(r);
-      const double gy = gap(1, y, y), gz = gap(2, z, z);
-      const double s2 = gy * gy + gz * gz;
-      if (s2 * h2 > lim) return;
-      int ja = 0, jb = 2;
-      { const double g = gap(0, cc[0] - 1, cc[0] - 1); if ((g * g + s2) * h2 > lim) ja = 1; }
-      { const double g = gap(0, cc[0] + 1, cc[0] + 1); if ((g * g + s2) * h2 > lim) jb = 1; }
-      scan2(ja == 0 ? s4[0] : s4[1], jb == 2 ? s4[3] : s4[2]);
-    };
-    if (active) {
-      scan2_row(rowA, sA);
-      scan2_row(rowB, sB);
-      if (ql > 0) {
-        const int y = cc[1] + row_dy(8), z = cc[2] + row_dz(8), x = cc[0] - 1 + (ql - 1);
-        const double gx = gap(0, x, x), gy = gap(1, y, y), gz = gap(2, z, z);
-        if ((gx * gx + gy * gy + gz * gz) * h2 <= lim) scan2(sC[0], sC[1]);
-      }
+      if (p < e) push2(dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p])), p);
     }
-    // The quad's queue is written and read by lanes of ONE wave: the LDS executes a wave's operations in issue order and
+    // A quad's segments are written and read by lanes of ONE wave: the LDS executes a wave's operations in issue order and
     // the scans above have reconverged, so no workgroup barrier is needed -- only a compiler fence.
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     // ---- pass 3: exact metric, ranking by all-pairs counting inside the quad ----
-    const uint32_t nq = qn[quad];
-    overflow = overflow || nq > (uint32_t)TILE_QCAP;
-    // (any lane's overflow flag must reach the whole quad)
-    overflow = (__ballot(overflow) >> ((threadIdx.x & 63) & ~3)) & 0xFull;
+    const uint32_t n0 = dpp_u32<DPP_QP_0000>(nmine), n1 = dpp_u32<DPP_QP_1111>(nmine), n2 = dpp_u32<DPP_QP_2222>(nmine),
+                   n3 = dpp_u32<DPP_QP_3333>(nmine);
+    const uint32_t p1 = n0, p2 = n0 + n1, p3 = p2 + n2, nq = p3 + n3;
+    const bool overflow = nq > (uint32_t)TILE_QCAP || n0 > (uint32_t)TILE_LCAP || n1 > (uint32_t)TILE_LCAP || n2 > (uint32_t)TILE_LCAP ||
+                          n3 > (uint32_t)TILE_LCAP;                                 // quad-uniform by construction
+#if defined(PT_ABLATE) && PT_ABLATE == 3
+    if (nq < 1000u) continue;                          // timing-only build: staging + passes 1, 2
+#endif
     double od[TILE_QCAP / 4];
     uint32_t oi[TILE_QCAP / 4];
     int rk[TILE_QCAP / 4];
 #pragma unroll
-    for (int j = 0; j < TILE_QCAP / 4; ++j) {          // my entries: ql, ql+4, ...
+    for (int j = 0; j < TILE_QCAP / 4; ++j) {          // my entries of the concatenated segments: ql, ql+4, ...
       const uint32_t e = (uint32_t)(4 * j + ql);
       od[j] = INFINITY; oi[j] = PT_NOIDX_U; rk[j] = 0;
-      if (e < nq && e < (uint32_t)TILE_QCAP) {
-        const RecF r = lrec[queue[quad * TILE_QCAP + e]];
+      if (e < nq && !overflow) {
+        const uint32_t seg = (uint32_t)(e >= p1) + (uint32_t)(e >= p2) + (uint32_t)(e >= p3);
+        const uint32_t off = e - (seg == 0 ? 0u : (seg == 1 ? p1 : (seg == 2 ? p2 : p3)));
+        const RecF r = lrec[queue[((threadIdx.x & ~3u) + seg) * TILE_LCAP + off]];
         od[j] = dist2(q, r);
         oi[j] = r.id;
       }
@@ -754,9 +742,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
         todo[atomicAdd(todo_n, 1u)] = t;
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    if (ql == 0) qn[quad] = 0;                         // same wave as every reader of this counter: ordered
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // next round's segment writes stay behind this round's reads
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -827,20 +813,20 @@ template void pt_launch_knn<RecD>(const GridParams&, const RecD*, const uint32_t
                                   const uint32_t*, const uint32_t*, hipStream_t);
 
 // tile kernel over all blocks; targets it cannot settle are appended to todo[*todo_n] (todo_n zeroed by the caller).
-// `small` selects the two-workgroups-per-CU geometry (regions of <= 4480 records).
+// `small` selects the two-workgroups-per-CU geometry (regions of <= PT_TILE_CAP_SMALL_* records).
 void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* cell_start, const RecF* tgt, const uint32_t* tblock_start, int k,
                         uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int small, hipStream_t s) {
   const uint32_t nb = (uint32_t)gp.nblocks;
 #define PT_TILE_LAUNCH(KK, CAP, TH) \
   hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n)
   if (small) {
-    if (k <= 8) PT_TILE_LAUNCH(8, 4480, 512);
-    else if (k <= 16) PT_TILE_LAUNCH(16, 4224, 512);
-    else PT_TILE_LAUNCH(32, 3968, 512);
+    if (k <= 8) PT_TILE_LAUNCH(8, PT_TILE_CAP_SMALL_8, 512);
+    else if (k <= 16) PT_TILE_LAUNCH(16, PT_TILE_CAP_SMALL_16, 512);
+    else PT_TILE_LAUNCH(32, PT_TILE_CAP_SMALL_16, 512);
   } else {
-    if (k <= 8) PT_TILE_LAUNCH(8, 8448, 768);
-    else if (k <= 16) PT_TILE_LAUNCH(16, 8448, 768);
-    else PT_TILE_LAUNCH(32, 8448, 768);
+    if (k <= 8) PT_TILE_LAUNCH(8, PT_TILE_CAP_LARGE, 768);
+    else if (k <= 16) PT_TILE_LAUNCH(16, PT_TILE_CAP_LARGE, 768);
+    else PT_TILE_LAUNCH(32, PT_TILE_CAP_LARGE, 768);
   }
 #undef PT_TILE_LAUNCH
 }
