@@ -448,7 +448,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
   constexpr int TILE_QCAP = TileQ<K>::CAP, TILE_LCAP = TileQ<K>::LCAP;
   __shared__ __attribute__((aligned(16))) RecF lrec[TILE_CAP];
   __shared__ uint16_t lstart[TILE_CELLS + 8];
-  __shared__ __attribute__((aligned(16))) uint16_t queue[TWG * TILE_LCAP];          // doubles as gstart[] during staging
+  __shared__ __attribute__((aligned(16))) uint16_t queue[TWG * (TILE_LCAP + 1)];          // doubles as gstart[] during staging
   __shared__ uint32_t wsum[NW];
   __shared__ uint32_t ptotal;
   uint32_t* gstart = reinterpret_cast<uint32_t*>(queue);
@@ -456,8 +456,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
   static_assert(TILE_CAP < 65536, "LDS offsets are 16-bit");
 
   const uint32_t b = blockIdx.x;
-  const uint32_t ts = tblock_start[b], te = tblock_start[b + 1];
-  if (ts == te) return;
+  const uint32_t ts = tblock_start[b], te = tblock_start[b + 1];   // (waited for only after the cell-table loads below are out)
   // block id -> cell origin of the block
   const uint32_t macro = b >> 9, m9 = b & 511u;
   const int bx = (int)(macro % (uint32_t)gp.mdim[0]) * 8 + (int)((m9 & 1u) | ((m9 >> 2) & 2u) | ((m9 >> 4) & 4u));
@@ -484,6 +483,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
       }
       sum += cnt[i];
     }
+    if (ts == te) return;                               // no targets in this block
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t incl = wave_incl_scan(sum);
     if (lane == 63) wsum[w] = incl;
@@ -628,10 +628,17 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
     }
     // the quad's K smallest: two bitonic merges through DPP (all lanes of the wave take part: no divergence here)
     quad_merge_sorted<K, DPP_QP_1032>(l32);
-    quad_merge_sorted<K, DPP_QP_2301>(l32);
-    float kv = l32[0];
+    float kv;
+    if (k == K) {                                      // only the K-th smallest is wanted: the largest of the bitonic lower half
+      kv = fminf(l32[0], dpp_f32<DPP_QP_2301>(l32[K - 1]));
 #pragma unroll
-    for (int j = 1; j < K; ++j) kv = (j == k - 1) ? l32[j] : kv;
+      for (int j = 1; j < K; ++j) kv = fmaxf(kv, fminf(l32[j], dpp_f32<DPP_QP_2301>(l32[K - 1 - j])));
+    } else {
+      quad_merge_sorted<K, DPP_QP_2301>(l32);
+      kv = l32[0];
+#pragma unroll
+      for (int j = 1; j < K; ++j) kv = (j == k - 1) ? l32[j] : kv;
+    }
     const float thr = kth_bound32(kv);
 #if defined(PT_ABLATE) && PT_ABLATE == 2
     if (thr >= 0.f) continue;                       // timing-only build: staging + pass 1 (results are garbage)
@@ -649,13 +656,13 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
     const float g2x[3] = {gapf(fx, -1) * gapf(fx, -1), 0.f, gapf(fx, 1) * gapf(fx, 1)};
     const float g2y[3] = {gapf(fy, -1) * gapf(fy, -1), gapf(fy, 0) * gapf(fy, 0), gapf(fy, 1) * gapf(fy, 1)};
     const float g2z[3] = {gapf(fz, -1) * gapf(fz, -1), gapf(fz, 0) * gapf(fz, 0), gapf(fz, 1) * gapf(fz, 1)};
-    uint16_t* myq = &queue[threadIdx.x * TILE_LCAP];
+    // branch-free append: the position is always stored at the segment's next slot and the count only moves when the
+    // candidate is within the bound (a rejected one is overwritten by its successor); slot TILE_LCAP takes the spill.
+    uint16_t* myq = &queue[threadIdx.x * (TILE_LCAP + 1)];
     uint32_t nmine = 0;
     auto push2 = [&](float x, uint32_t p) {
-      if (x <= thr) {
-        if (nmine < (uint32_t)TILE_LCAP) myq[nmine] = (uint16_t)p;
-        ++nmine;
-      }
+      myq[nmine < (uint32_t)TILE_LCAP ? nmine : (uint32_t)TILE_LCAP] = (uint16_t)p;
+      nmine += (x <= thr) ? 1u : 0u;
     };
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
@@ -696,23 +703,45 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
       if (e < nq && !overflow) {
         const uint32_t seg = (uint32_t)(e >= p1) + (uint32_t)(e >= p2) + (uint32_t)(e >= p3);
         const uint32_t off = e - (seg == 0 ? 0u : (seg == 1 ? p1 : (seg == 2 ? p2 : p3)));
-        const RecF r = lrec[queue[((threadIdx.x & ~3u) + seg) * TILE_LCAP + off]];
+        const RecF r = lrec[queue[((threadIdx.x & ~3u) + seg) * (TILE_LCAP + 1) + off]];
         od[j] = dist2(q, r);
         oi[j] = r.id;
       }
     }
+    // Ranking counts, for each of my entries, the queue entries with a smaller distance.  Equal distances (rare) leave
+    // two entries with the same count: the ranks then do not add up to 0 + 1 + ... + (nq-1) and the quad redoes the count
+    // under the full order (d2, index).
+    auto rank_all = [&](auto lt) {
 #pragma unroll
-    for (int j = 0; j < TILE_QCAP / 4; ++j) {          // round j: the four lanes' j-th entries visit every lane
-      if ((uint32_t)(4 * j) < nq) {                    // quad-uniform
-        const double b0 = dpp_f64<DPP_QP_0000>(od[j]), b1 = dpp_f64<DPP_QP_1111>(od[j]), b2 = dpp_f64<DPP_QP_2222>(od[j]),
-                     b3 = dpp_f64<DPP_QP_3333>(od[j]);
-        const uint32_t i0 = dpp_u32<DPP_QP_0000>(oi[j]), i1 = dpp_u32<DPP_QP_1111>(oi[j]), i2 = dpp_u32<DPP_QP_2222>(oi[j]),
-                       i3 = dpp_u32<DPP_QP_3333>(oi[j]);
+      for (int j = 0; j < TILE_QCAP / 4; ++j) {        // round j: the four lanes' j-th entries visit every lane
+        if ((uint32_t)(4 * j) < nq) {                  // quad-uniform
+          const double b0 = dpp_f64<DPP_QP_0000>(od[j]), b1 = dpp_f64<DPP_QP_1111>(od[j]), b2 = dpp_f64<DPP_QP_2222>(od[j]),
+                       b3 = dpp_f64<DPP_QP_3333>(od[j]);
+          const uint32_t i0 = dpp_u32<DPP_QP_0000>(oi[j]), i1 = dpp_u32<DPP_QP_1111>(oi[j]), i2 = dpp_u32<DPP_QP_2222>(oi[j]),
+                         i3 = dpp_u32<DPP_QP_3333>(oi[j]);
 #pragma unroll
-        for (int m = 0; m < TILE_QCAP / 4; ++m) {
-          rk[m] += (int)key_lt(b0, i0, od[m], oi[m]) + (int)key_lt(b1, i1, od[m], oi[m]) + (int)key_lt(b2, i2, od[m], oi[m]) +
-                   (int)key_lt(b3, i3, od[m], oi[m]);
+          for (int m = 0; m < TILE_QCAP / 4; ++m) {
+            if ((uint32_t)(4 * m) < nq)                // quad-uniform: slots beyond the queue hold +inf and rank nowhere
+              rk[m] += (int)lt(b0, i0, od[m], oi[m]) + (int)lt(b1, i1, od[m], oi[m]) + (int)lt(b2, i2, od[m], oi[m]) +
+                       (int)lt(b3, i3, od[m], oi[m]);
+          }
         }
+      }
+    };
+    if constexpr (K > 16) {                           // (register budget: one ranking body only)
+      rank_all([](double ad, uint32_t ai, double bd, uint32_t bi) { return key_lt(ad, ai, bd, bi); });
+    } else {
+      rank_all([](double ad, uint32_t, double bd, uint32_t) { return ad < bd; });
+      int rs = 0;
+#pragma unroll
+      for (int j = 0; j < TILE_QCAP / 4; ++j) rs += (oi[j] != PT_NOIDX_U) ? rk[j] : 0;
+      rs += (int)dpp_u32<DPP_QP_1032>((uint32_t)rs);
+      rs += (int)dpp_u32<DPP_QP_2301>((uint32_t)rs);
+      const uint32_t nv = overflow ? 0u : nq;
+      if ((uint32_t)rs != nv * (nv - 1u) / 2u) {       // quad-uniform
+#pragma unroll
+        for (int j = 0; j < TILE_QCAP / 4; ++j) rk[j] = 0;
+        rank_all([](double ad, uint32_t ai, double bd, uint32_t bi) { return key_lt(ad, ai, bd, bi); });
       }
     }
     // exact k-th squared distance of ring 1 (rank k-1), known to one lane -> quad minimum
