@@ -448,11 +448,14 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
   constexpr int TILE_QCAP = TileQ<K>::CAP, TILE_LCAP = TileQ<K>::LCAP;
   __shared__ __attribute__((aligned(16))) RecF lrec[TILE_CAP];
   __shared__ uint16_t lstart[TILE_CELLS + 8];
-  __shared__ __attribute__((aligned(16))) uint16_t queue[TWG * (TILE_LCAP + 1)];          // doubles as gstart[] during staging
+  __shared__ __attribute__((aligned(16))) uint16_t queue[TWG * (TILE_LCAP + 1)];          // doubles as rowdesc[] during staging
   __shared__ uint32_t wsum[NW];
   __shared__ uint32_t ptotal;
-  uint32_t* gstart = reinterpret_cast<uint32_t*>(queue);
-  static_assert(sizeof(queue) >= TILE_CELLS * sizeof(uint32_t), "gstart aliases the queue");
+  // per region row: global starts of its left halo cell / its run of 8 cells / its right halo cell, and the LDS offsets
+  // of cells 0, 1, 9 and of the next row (two 16-bit pairs)
+  uint4* rowdesc = reinterpret_cast<uint4*>(queue);
+  uint32_t* rowdesc_e = reinterpret_cast<uint32_t*>(queue) + 4 * TILE_R * TILE_R;
+  static_assert(sizeof(queue) >= 5 * TILE_R * TILE_R * sizeof(uint32_t), "rowdesc aliases the queue");
   static_assert(TILE_CAP < 65536, "LDS offsets are 16-bit");
 
   const uint32_t b = blockIdx.x;
@@ -464,41 +467,56 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
   const int bz = (int)(macro / (uint32_t)(gp.mdim[0] * gp.mdim[1])) * 8 + (int)(((m9 >> 2) & 1u) | ((m9 >> 4) & 2u) | ((m9 >> 6) & 4u));
   const int ox = bx * 8 - 1, oy = by * 8 - 1, oz = bz * 8 - 1;          // cell coordinates of region cell (0,0,0)
 
-  // ---- A: region cell table (global start + count of each of the 1000 cells), LDS offsets by a workgroup scan
-  {
-    uint32_t cnt[4], sum = 0;
+  // ---- A: region cell table (global start + LDS offset of each of the 1000 cells).  One thread per region ROW (y, z):
+  //         cells x = 1..8 of a row are eight consecutive keys of one block, so a row needs three key computations
+  //         (left halo cell, the run, right halo cell) and 13 table words.  Waves 0 and 1 do this; the rest go to the barrier.
+  constexpr int NROWS = TILE_R * TILE_R;
+  if (threadIdx.x < 128) {
+    const int row = threadIdx.x;
+    uint32_t g[TILE_R], cnt[TILE_R], sum = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = threadIdx.x * 4 + i;
-      cnt[i] = 0;
-      if (c < TILE_CELLS) {
-        const int x = ox + c % TILE_R, y = oy + (c / TILE_R) % TILE_R, z = oz + c / (TILE_R * TILE_R);
-        uint32_t gs = 0;
-        if (x >= 0 && x < gp.dim[0] && y >= 0 && y < gp.dim[1] && z >= 0 && z < gp.dim[2]) {
-          const uint32_t key = cell_key(gp, x, y, z);
-          gs = cs[key];
-          cnt[i] = cs[key + 1] - gs;
-        }
-        gstart[c] = gs;
+    for (int i = 0; i < TILE_R; ++i) { g[i] = 0; cnt[i] = 0; }
+    if (row < NROWS) {
+      const int y = oy + row % TILE_R, z = oz + row / TILE_R;
+      if (y >= 0 && y < gp.dim[1] && z >= 0 && z < gp.dim[2]) {
+        const uint32_t km = cell_key(gp, ox + 1, y, z);              // cells ox+1 .. ox+8: keys km .. km+7 (32-byte aligned)
+        const uint4 m0 = *reinterpret_cast<const uint4*>(cs + km), m1 = *reinterpret_cast<const uint4*>(cs + km + 4);
+        const uint32_t m8 = cs[km + 8];
+        uint32_t l0 = 0, l1 = 0, r0 = 0, r1 = 0;
+        if (ox >= 0) { const uint32_t kl = cell_key(gp, ox, y, z); l0 = cs[kl]; l1 = cs[kl + 1]; }
+        if (ox + 9 < gp.dim[0]) { const uint32_t kr = cell_key(gp, ox + 9, y, z); r0 = cs[kr]; r1 = cs[kr + 1]; }
+        g[0] = l0; g[1] = m0.x; g[2] = m0.y; g[3] = m0.z; g[4] = m0.w; g[5] = m1.x; g[6] = m1.y; g[7] = m1.z; g[8] = m1.w; g[9] = r0;
+        cnt[0] = l1 - l0; cnt[9] = r1 - r0;
+        cnt[1] = m0.y - m0.x; cnt[2] = m0.z - m0.y; cnt[3] = m0.w - m0.z; cnt[4] = m1.x - m0.w;
+        cnt[5] = m1.y - m1.x; cnt[6] = m1.z - m1.y; cnt[7] = m1.w - m1.z; cnt[8] = m8 - m1.w;
       }
-      sum += cnt[i];
+#pragma unroll
+      for (int i = 0; i < TILE_R; ++i) sum += cnt[i];
     }
-    if (ts == te) return;                               // no targets in this block
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (ts == te) return;                               // no targets in this block (whole workgroup: ts, te are uniform)
     const uint32_t incl = wave_incl_scan(sum);
-    if (lane == 63) wsum[w] = incl;
-    __syncthreads();
-    uint32_t off = 0, tot = 0;
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();                       // (waves 0 and 1 only meet here: see below)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t w0 = wsum[0], w1 = wsum[1];
+    uint32_t ex = (threadIdx.x >= 64 ? w0 : 0u) + incl - sum;
+    if (row < NROWS) {
+      uint32_t lo[TILE_R + 1];
 #pragma unroll
-    for (int i = 0; i < NW; ++i) { const uint32_t ws = wsum[i]; if (i < w) off += ws; tot += ws; }
-    uint32_t ex = off + incl - sum;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = threadIdx.x * 4 + i;
-      if (c < TILE_CELLS) lstart[c] = (uint16_t)(ex < 65535u ? ex : 65535u);
-      ex += cnt[i];
+      for (int i = 0; i < TILE_R; ++i) {
+        lo[i] = ex < 65535u ? ex : 65535u;
+        lstart[row * TILE_R + i] = (uint16_t)lo[i];
+        ex += cnt[i];
+      }
+      lo[TILE_R] = ex < 65535u ? ex : 65535u;
+      rowdesc[row] = make_uint4(g[0], g[1], g[9], lo[0] | (lo[1] << 16));
+      rowdesc_e[row] = lo[9] | (lo[TILE_R] << 16);
     }
-    if (threadIdx.x == 0) { lstart[TILE_CELLS] = (uint16_t)(tot < 65535u ? tot : 65535u); ptotal = tot; }
+    if (threadIdx.x == 0) { const uint32_t tot = w0 + w1; lstart[TILE_CELLS] = (uint16_t)(tot < 65535u ? tot : 65535u); ptotal = tot; }
+  } else {
+    if (ts == te) return;
+    __builtin_amdgcn_s_barrier();                       // pairs with the barrier between the two table waves' scan halves
   }
   __syncthreads();
   const uint32_t P = ptotal;
@@ -506,33 +524,32 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
     for (uint32_t t = ts + threadIdx.x; t < te; t += TWG) todo[atomicAdd(todo_n, 1u)] = t;
     return;
   }
-  // ---- B: stage the region.  Cells x = 1..8 of a region row are one contiguous run in HBM and in LDS: a wave copies
-  //         a row with two instructions (<= 128 records); the 200 halo cells (x = 0 and 9) are copied by 8-lane groups.
-  //         With one workgroup per CU nothing else hides HBM latency, so every load of a batch is issued before the
-  //         first LDS store: two exposed latencies per tile instead of one per row.
+  // ---- B: stage the region, HBM -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, per-lane
+  //         source address; no staging registers).  Cells x = 1..8 of a region row are one contiguous run in HBM and in
+  //         LDS: two DMA instructions per row (<= 128 records) with wave-uniform (scalar) addresses; the 200 halo cells
+  //         (x = 0 and 9) follow through registers.  Every load of the tile is in flight before the first wait.
   {
     const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(src);     // records move as raw 16-byte words
     uint4* l4 = reinterpret_cast<uint4*>(lrec);
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int NROWS = TILE_R * TILE_R;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     constexpr int RPW = (NROWS + NW - 1) / NW;                      // rows per wave (9 or 13)
     bool long_rows = false;
-    // rows go HBM -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, per-lane source address),
-    // no staging registers: every row of the wave and the halo loads below are in flight together -- ONE exposed latency.
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int rr = w + i * NW;
       if (rr < NROWS) {                                             // wave-uniform
-        const int c1 = rr * TILE_R + 1;
-        const uint32_t la = lstart[c1], len = lstart[c1 + 8] - la, ga = gstart[c1];
-        if ((uint32_t)lane < len) glds16(src4 + ga + lane, l4 + la);
-        if ((uint32_t)lane + 64u < len) glds16(src4 + ga + lane + 64u, l4 + la + 64u);
-        long_rows |= len > 128u;
+        const uint32_t g1 = __builtin_amdgcn_readfirstlane(rowdesc[rr].y);
+        const uint32_t p01 = __builtin_amdgcn_readfirstlane(rowdesc[rr].w), p9 = __builtin_amdgcn_readfirstlane(rowdesc_e[rr]);
+        const uint32_t la1 = p01 >> 16, nm = (p9 & 0xFFFFu) - la1;
+        if ((uint32_t)lane < nm) glds16(src4 + g1 + lane, l4 + la1);
+        if ((uint32_t)lane + 64u < nm) glds16(src4 + g1 + 64 + lane, l4 + la1 + 64u);
+        long_rows |= nm > 128u;
       }
     }
+    // halo cells: 16 records would waste a 64-lane DMA each, so 8-lane groups move them through registers
     const int g8 = threadIdx.x >> 3, l8 = threadIdx.x & 7;
     constexpr int NHALO = 2 * NROWS;
-    constexpr int HC = (NHALO + TWG / 8 - 1) / (TWG / 8);           // 3 halo cells per 8-lane group
+    constexpr int HC = (NHALO + TWG / 8 - 1) / (TWG / 8);           // halo cells per 8-lane group
     uint4 h0[HC], h1[HC];
     uint32_t hla[HC], hlen[HC];
     bool long_cells = false;
@@ -543,7 +560,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
       const int c = (hc >> 1) * TILE_R + ((hc & 1) ? TILE_R - 1 : 0);
       hla[i] = lstart[c];
       hlen[i] = hcr < NHALO ? lstart[c + 1] - hla[i] : 0u;
-      const uint32_t ga = gstart[c];
+      const uint32_t ga = (hc & 1) ? rowdesc[hc >> 1].z : rowdesc[hc >> 1].x;
       h0[i] = make_uint4(0, 0, 0, 0); h1[i] = make_uint4(0, 0, 0, 0);
       if ((uint32_t)l8 < hlen[i]) h0[i] = src4[ga + l8];
       if ((uint32_t)l8 + 8u < hlen[i]) h1[i] = src4[ga + l8 + 8u];
@@ -555,21 +572,20 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
       if ((uint32_t)l8 + 8u < hlen[i]) l4[hla[i] + l8 + 8u] = h1[i];
     }
     if (long_rows) {                                                // very dense rows: the rest synchronously
-      for (int row = w; row < NROWS; row += NW) {
-        const int c1 = row * TILE_R + 1;
-        const uint32_t a0 = lstart[c1], n0 = lstart[c1 + 8] - a0, ga = gstart[c1];
-        for (uint32_t p = lane + 128u; p < n0; p += 64) l4[a0 + p] = src4[ga + p];
+      for (int rr = w; rr < NROWS; rr += NW) {
+        const uint32_t g1 = rowdesc[rr].y, la1 = rowdesc[rr].w >> 16, nm = (rowdesc_e[rr] & 0xFFFFu) - la1;
+        for (uint32_t p = lane + 128u; p < nm; p += 64) l4[la1 + p] = src4[g1 + p];
       }
     }
     if (long_cells) {
       for (int hc = g8; hc < NHALO; hc += TWG / 8) {
         const int c = (hc >> 1) * TILE_R + ((hc & 1) ? TILE_R - 1 : 0);
-        const uint32_t a0 = lstart[c], n0 = lstart[c + 1] - a0, ga = gstart[c];
+        const uint32_t a0 = lstart[c], n0 = lstart[c + 1] - a0, ga = (hc & 1) ? rowdesc[hc >> 1].z : rowdesc[hc >> 1].x;
         for (uint32_t p = l8 + 16u; p < n0; p += 8) l4[a0 + p] = src4[ga + p];
       }
     }
   }
-  __syncthreads();                                  // gstart is dead from here on: the queue takes its place
+  __syncthreads();                                  // rowdesc is dead from here on: the queue takes its place
 #if defined(PT_ABLATE) && PT_ABLATE == 1
   if (lrec[threadIdx.x % (P ? P : 1u)].id == 0xFFFFFFFEu) out_idx[0] = 1;   // keeps the staging alive
   return;                                           // timing-only build: staging cost alone (results are garbage)
