@@ -405,6 +405,13 @@ __device__ inline RecF lds_rec(const RecF* p) {
   r.x = v.x; r.y = v.y; r.z = v.z; r.id = __float_as_uint(v.w);
   return r;
 }
+// two staged records, both reads issued before either is waited for
+__device__ inline void lds_rec2(const RecF* p, const RecF* q, RecF& a, RecF& b) {
+  const float4 u = *reinterpret_cast<const float4*>(p), v = *reinterpret_cast<const float4*>(q);
+  asm volatile("" ::"v"(u.w), "v"(v.w));
+  a.x = u.x; a.y = u.y; a.z = u.z; a.id = __float_as_uint(u.w);
+  b.x = v.x; b.y = v.y; b.z = v.z; b.id = __float_as_uint(v.w);
+}
 // d32 is computed from exact fp32 inputs with 3 sub, 1 mul, 2 fma: relative error < 2^-21 (all terms >= 0).
 // If b = k-th smallest d32 of a candidate set, then k candidates have exact d2 <= b*(1+2^-21), so the exact k-th d2
 // D_k <= b*(1+2^-21), and every candidate with exact d2 <= D_k has d32 <= b*(1+2^-21)^2 < b*(1+2^-18).
@@ -629,15 +636,22 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
 #pragma unroll
       for (int j = 1; j < K; ++j) { const float cur = l32[j]; l32[j] = __builtin_amdgcn_fmed3f(x, prev, cur); prev = cur; }
     };
+    {
+      uint32_t ps[4], pe[4];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const int c = cbase + ((sz + (o >> 1)) * TILE_R + (sy + (o & 1))) * TILE_R + 1 + sx;
-      const uint32_t e = lstart[c + 2];
-      uint32_t p = lstart[c] + ql;
-      if (active) {
-        for (; p + 4 < e; p += 8) {                    // two LDS reads in flight per lane
-          const float x0 = dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p])), x1 = dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p + 4]));
-          push1(x0); push1(x1);
+      for (int o = 0; o < 4; ++o) {                    // all eight table reads in flight together
+        const int c = cbase + ((sz + (o >> 1)) * TILE_R + (sy + (o & 1))) * TILE_R + 1 + sx;
+        ps[o] = (uint32_t)lstart[c] + ql;
+        pe[o] = active ? (uint32_t)lstart[c + 2] : 0u;
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        uint32_t p = ps[o];
+        const uint32_t e = pe[o];
+        for (; p + 4 < e; p += 8) {
+          RecF a, b;
+          lds_rec2(&lrec[p], &lrec[p + 4], a, b);
+          push1(dist2_f32(tr.x, tr.y, tr.z, a)); push1(dist2_f32(tr.x, tr.y, tr.z, b));
         }
         if (p < e) push1(dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p])));
       }
@@ -680,20 +694,29 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
       myq[nmine < (uint32_t)TILE_LCAP ? nmine : (uint32_t)TILE_LCAP] = (uint16_t)p;
       nmine += (x <= thr) ? 1u : 0u;
     };
+    {
+      uint32_t qs[9], qe[9];
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const int dy = r % 3 - 1, dz = r / 3 - 1;
-      const int c = cbase + (dz * TILE_R + dy) * TILE_R;
-      const float s2 = g2y[dy + 1] + g2z[dz + 1];
-      const bool row_on = active && !(s2 * h2f > thr);
-      const bool lo_on = !((g2x[0] + s2) * h2f > thr), hi_on = !((g2x[2] + s2) * h2f > thr);
-      const uint32_t e = row_on ? (uint32_t)lstart[hi_on ? c + 3 : c + 2] : 0u;
-      uint32_t p = (uint32_t)lstart[lo_on ? c : c + 1] + ql;
-      for (; p + 4 < e; p += 8) {
-        const float x0 = dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p])), x1 = dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p + 4]));
-        push2(x0, p); push2(x1, p + 4);
+      for (int r = 0; r < 9; ++r) {                    // the runs of all nine rows first: their table reads overlap
+        const int dy = r % 3 - 1, dz = r / 3 - 1;
+        const int c = cbase + (dz * TILE_R + dy) * TILE_R;
+        const float s2 = g2y[dy + 1] + g2z[dz + 1];
+        const bool row_on = active && !(s2 * h2f > thr);
+        const bool lo_on = !((g2x[0] + s2) * h2f > thr), hi_on = !((g2x[2] + s2) * h2f > thr);
+        qe[r] = row_on ? (uint32_t)lstart[hi_on ? c + 3 : c + 2] : 0u;
+        qs[r] = (uint32_t)lstart[lo_on ? c : c + 1] + ql;
       }
-      if (p < e) push2(dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p])), p);
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        uint32_t p = qs[r];
+        const uint32_t e = qe[r];
+        for (; p + 4 < e; p += 8) {
+          RecF a, b;
+          lds_rec2(&lrec[p], &lrec[p + 4], a, b);
+          push2(dist2_f32(tr.x, tr.y, tr.z, a), p); push2(dist2_f32(tr.x, tr.y, tr.z, b), p + 4);
+        }
+        if (p < e) push2(dist2_f32(tr.x, tr.y, tr.z, lds_rec(&lrec[p])), p);
+      }
     }
     // A quad's segments are written and read by lanes of ONE wave: the LDS executes a wave's operations in issue order and
     // the scans above have reconverged, so no workgroup barrier is needed -- only a compiler fence.
