@@ -572,8 +572,12 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
   mark(1);
   if (n) {
     hipLaunchKernelGGL(colapply_kernel, dim3(ngroups), dim3(WG), 0, s, tb.chunk_hist, (int)nchunks, (int)nmacro, tb.chunk_gsum, tb.start1);
-    hipLaunchKernelGGL((scatter_chunk_kernel<PlanarLoader<T>, ITEMS_S, SW>), dim3(nchunks), dim3(SW), 0, s, pl, out_final, gp, b1, n, chunk_tiles,
-                       tb.chunk_hist);
+    if (chunk_tiles % 2 == 0)     // big clouds: 1024-thread workgroups, tiles twice as long -> twice the bytes per bin and tile
+      hipLaunchKernelGGL((scatter_chunk_kernel<PlanarLoader<T>, ITEMS_S, 2 * SW>), dim3(nchunks), dim3(2 * SW), 0, s, pl, out_final, gp, b1, n,
+                         chunk_tiles / 2, tb.chunk_hist);
+    else
+      hipLaunchKernelGGL((scatter_chunk_kernel<PlanarLoader<T>, ITEMS_S, SW>), dim3(nchunks), dim3(SW), 0, s, pl, out_final, gp, b1, n, chunk_tiles,
+                         tb.chunk_hist);
   }
   mark(2);
   RecLoader<Rec> rl{out_final};
