@@ -46,7 +46,8 @@ struct pt_ctx {
   int src_type = -1;           // PT_F32 / PT_F64
   uint64_t n = 0, n_total = 0; // resident points; size of the attribute table
   DevBuf in_xyz, in_gidx, attr, rec, rec_tmp, cell_start;
-  bool has_gidx = false, has_attr = false, built = false;
+  DevBuf posattr;              // fp32 clouds: {position, attributes} by original index for the PCA pass, built on first use
+  bool has_gidx = false, has_attr = false, built = false, posattr_valid = false;
   GridParams gp{};
   SortTables stb{};
   DevBuf stb_mem;
@@ -402,7 +403,7 @@ void pt_ctx_destroy(pt_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in_xyz, &c->in_gidx, &c->attr, &c->rec, &c->rec_tmp, &c->cell_start, &c->stb_mem, &c->t_xyz, &c->t_gidx, &c->trec,
-                   &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo};
+                   &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr};
   for (DevBuf* b : all) release(c, *b);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);
@@ -466,7 +467,7 @@ int pt_build_aos(pt_ctx* c, const pt_point* cloud, uint64_t n) {
   { int r = copy_in(c, c->aos_stage.p, cloud, n * sizeof(pt_point), 0); if (r) return r; }
   double* x = (double*)c->in_xyz.p;
   pt_launch_aos_split(c->aos_stage.p, (uint32_t)n, x, x + n, x + 2 * n, (Attr*)c->attr.p, c->stream);
-  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false;
+  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false; c->posattr_valid = false;
   return rebuild(c);
 }
 
@@ -481,6 +482,7 @@ int pt_build_soa_indexed(pt_ctx* c, const void* xyz, int xyz_type, const uint32_
   }
   c->src_type = xyz_type; c->n = n; c->has_gidx = gidx != nullptr; c->built = false;
   if (!gidx) { c->n_total = n; c->has_attr = false; }
+  c->posattr_valid = false;
   return rebuild(c);
 }
 
@@ -499,7 +501,7 @@ int pt_set_attributes(pt_ctx* c, const uint8_t* rgb, const float* nrm, uint64_t 
   }
   pt_launch_pack_attr(drgb, dnrm, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
   c->n_total = n_total;
-  c->has_attr = true;
+  c->has_attr = true; c->posattr_valid = false;
   return finish(c);
 }
 
@@ -536,7 +538,7 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
   else { double* x = (double*)c->in_xyz.p; pt_launch_synth_xyz<double>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream); }
   RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
   pt_launch_synth_attr(seed, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
-  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false;
+  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false; c->posattr_valid = false;
   return rebuild(c);
 }
 
@@ -699,7 +701,18 @@ int pt_pca_normals_dev(pt_ctx* c, const uint32_t* idx_dev, uint64_t m, int k, fl
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   const Attr* at = c->has_attr ? (const Attr*)c->attr.p : nullptr;
-  if (c->src_type == PT_F32) { const float* x = (const float*)c->in_xyz.p; pt_launch_pca<float>(idx_dev, (uint32_t)m, k, x, x + c->n, x + 2 * c->n, (uint32_t)c->n, at, nrm_out_dev, c->stream); }
+  if (c->src_type == PT_F32) {
+    // one 32-byte gather per neighbour instead of four 4..16-byte ones: the table depends on the cloud only, so it is
+    // built on the first call after an upload and reused by every later one (rebuilds of the grid do not touch it)
+    const float* x = (const float*)c->in_xyz.p;
+    if (!c->posattr_valid) {
+      RES(c, c->posattr, std::max<uint64_t>(c->n, 1) * 32);
+      pt_launch_pack_posattr(x, x + c->n, x + 2 * c->n, at, (uint32_t)c->n, c->posattr.p, c->stream);
+      c->posattr_valid = true;
+      HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    }
+    pt_launch_pca_posattr(idx_dev, (uint32_t)m, k, c->posattr.p, (uint32_t)c->n, at ? 1 : 0, nrm_out_dev, c->stream);
+  }
   else { const double* x = (const double*)c->in_xyz.p; pt_launch_pca<double>(idx_dev, (uint32_t)m, k, x, x + c->n, x + 2 * c->n, (uint32_t)c->n, at, nrm_out_dev, c->stream); }
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   HIPCHK(c, hipGetLastError());

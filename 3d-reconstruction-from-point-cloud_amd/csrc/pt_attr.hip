@@ -193,12 +193,24 @@ __device__ inline void jacobi3(double (&a)[3][3], double (&v)[3][3]) {
   }
 }
 
-template <class T>
-__global__ __launch_bounds__(WG) void pca_kernel(const uint32_t* __restrict__ idx, uint32_t m, int k, const T* __restrict__ x,
-                                                 const T* __restrict__ y, const T* __restrict__ z, uint32_t n, const Attr* __restrict__ attr,
-                                                 float* __restrict__ nrm_out) {
-  const uint32_t t = blockIdx.x * WG + threadIdx.x;
-  if (t >= m) return;
+// position + attributes of one source point by ORIGINAL index, 32 bytes: what the PCA pass gathers per neighbour (one
+// sector instead of four: x, y, z and the attribute record live in four different arrays)
+struct PosAttr { float x, y, z; uint32_t rgba; float nx, ny, nz; uint32_t pad; };
+static_assert(sizeof(PosAttr) == 32, "PosAttr is two 16-byte words");
+
+__global__ __launch_bounds__(WG) void pack_posattr_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                          const Attr* __restrict__ attr, uint32_t n, PosAttr* __restrict__ out) {
+  const uint32_t i = blockIdx.x * WG + threadIdx.x;
+  if (i >= n) return;
+  PosAttr r;
+  r.x = x[i]; r.y = y[i]; r.z = z[i]; r.rgba = 0; r.nx = r.ny = r.nz = 0.f; r.pad = 0;
+  if (attr) { const Attr a = attr[i]; r.rgba = a.rgba; r.nx = a.nx; r.ny = a.ny; r.nz = a.nz; }
+  out[i] = r;
+}
+
+// PCA normal of one target from its neighbours: `fetch(id, p, nrm)` yields the neighbour's position (fp64) and normal
+template <class Fetch>
+__device__ inline void pca_one(const uint32_t* __restrict__ idx, uint32_t t, int k, uint32_t n, bool has_attr, float* __restrict__ nrm_out, Fetch fetch) {
   // one gather pass: moments about the first neighbour (a shift keeps Sum(dd^T) - Sum(d)Sum(d)^T/n free of cancellation)
   double mn[3] = {0, 0, 0}, sd[3] = {0, 0, 0}, o[3] = {0, 0, 0};
   double cv[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -206,7 +218,9 @@ __global__ __launch_bounds__(WG) void pca_kernel(const uint32_t* __restrict__ id
   for (int j = 0; j < k; ++j) {
     const uint32_t id = idx[(size_t)t * k + j];
     if (id == PT_NOIDX_U || id >= n) continue;
-    const double p[3] = {(double)x[id], (double)y[id], (double)z[id]};
+    double p[3];
+    float an[3];
+    fetch(id, p, an);
     if (ke == 0) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
     const double d[3] = {p[0] - o[0], p[1] - o[1], p[2] - o[2]};
 #pragma unroll
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(WG) void pca_kernel(const uint32_t* __restrict__ id
       for (int b = 0; b < 3; ++b) cv[a][b] += d[a] * d[b];
     }
     ++ke;
-    if (attr) { const Attr at = attr[id]; mn[0] += (double)at.nx; mn[1] += (double)at.ny; mn[2] += (double)at.nz; }
+    if (has_attr) { mn[0] += (double)an[0]; mn[1] += (double)an[1]; mn[2] += (double)an[2]; }
   }
   float* o3 = nrm_out + 3 * (size_t)t;
   if (ke < 3) { o3[0] = 0.f; o3[1] = 0.f; o3[2] = 1.f; return; }
@@ -232,9 +246,32 @@ __global__ __launch_bounds__(WG) void pca_kernel(const uint32_t* __restrict__ id
   else if (e1 <= e2) { nn[0] = v[0][1]; nn[1] = v[1][1]; nn[2] = v[2][1]; }
   else { nn[0] = v[0][2]; nn[1] = v[1][2]; nn[2] = v[2][2]; }
   const double len = sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
-  const double ref = attr ? (nn[0] * mn[0] + nn[1] * mn[1] + nn[2] * mn[2]) : nn[2];
+  const double ref = has_attr ? (nn[0] * mn[0] + nn[1] * mn[1] + nn[2] * mn[2]) : nn[2];
   const double sgn = (ref < 0 ? -1.0 : 1.0) / len;
   o3[0] = (float)(nn[0] * sgn); o3[1] = (float)(nn[1] * sgn); o3[2] = (float)(nn[2] * sgn);
+}
+
+template <class T>
+__global__ __launch_bounds__(WG) void pca_kernel(const uint32_t* __restrict__ idx, uint32_t m, int k, const T* __restrict__ x,
+                                                 const T* __restrict__ y, const T* __restrict__ z, uint32_t n, const Attr* __restrict__ attr,
+                                                 float* __restrict__ nrm_out) {
+  const uint32_t t = blockIdx.x * WG + threadIdx.x;
+  if (t >= m) return;
+  pca_one(idx, t, k, n, attr != nullptr, nrm_out, [&](uint32_t id, double (&p)[3], float (&an)[3]) {
+    p[0] = (double)x[id]; p[1] = (double)y[id]; p[2] = (double)z[id];
+    if (attr) { const Attr at = attr[id]; an[0] = at.nx; an[1] = at.ny; an[2] = at.nz; }
+  });
+}
+
+__global__ __launch_bounds__(WG) void pca_pa_kernel(const uint32_t* __restrict__ idx, uint32_t m, int k, const PosAttr* __restrict__ pa, uint32_t n,
+                                                    int has_attr, float* __restrict__ nrm_out) {
+  const uint32_t t = blockIdx.x * WG + threadIdx.x;
+  if (t >= m) return;
+  pca_one(idx, t, k, n, has_attr != 0, nrm_out, [&](uint32_t id, double (&p)[3], float (&an)[3]) {
+    const float4 a = reinterpret_cast<const float4*>(pa)[2 * (size_t)id], b = reinterpret_cast<const float4*>(pa)[2 * (size_t)id + 1];
+    p[0] = (double)a.x; p[1] = (double)a.y; p[2] = (double)a.z;
+    an[0] = b.x; an[1] = b.y; an[2] = b.z;
+  });
 }
 
 // fp16 planar xyz -> fp32 planar xyz (exact widening): fp16 clouds run through the fp32 path unchanged
@@ -296,6 +333,14 @@ template void pt_launch_pca<float>(const uint32_t*, uint32_t, int, const float*,
                                    hipStream_t);
 template void pt_launch_pca<double>(const uint32_t*, uint32_t, int, const double*, const double*, const double*, uint32_t, const Attr*, float*,
                                     hipStream_t);
+void pt_launch_pack_posattr(const float* x, const float* y, const float* z, const Attr* attr, uint32_t n, void* out, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(pack_posattr_kernel, grid_for(n), dim3(WG), 0, s, x, y, z, attr, n, (PosAttr*)out);
+}
+void pt_launch_pca_posattr(const uint32_t* idx, uint32_t m, int k, const void* posattr, uint32_t n, int has_attr, float* nrm_out, hipStream_t s) {
+  if (!m) return;
+  hipLaunchKernelGGL(pca_pa_kernel, grid_for(m), dim3(WG), 0, s, idx, m, k, (const PosAttr*)posattr, n, has_attr, nrm_out);
+}
 void pt_launch_iota(uint32_t* p, uint32_t n, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(WG), 0, s, p, n);

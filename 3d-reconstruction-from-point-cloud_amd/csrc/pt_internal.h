@@ -79,4 +79,7 @@ void pt_launch_blend(const uint32_t* idx, const double* d2, uint32_t m, int k, i
 template <class T>
 void pt_launch_pca(const uint32_t* idx, uint32_t m, int k, const T* x, const T* y, const T* z, uint32_t n, const Attr* attr,
                    float* nrm_out, hipStream_t s);
+// fp32 clouds: 32-byte {position, attributes} records by original index (built once per cloud) and the PCA pass over them
+void pt_launch_pack_posattr(const float* x, const float* y, const float* z, const Attr* attr, uint32_t n, void* out, hipStream_t s);
+void pt_launch_pca_posattr(const uint32_t* idx, uint32_t m, int k, const void* posattr, uint32_t n, int has_attr, float* nrm_out, hipStream_t s);
 void pt_launch_iota(uint32_t* p, uint32_t n, hipStream_t s);
