@@ -426,18 +426,19 @@ constexpr int DPP_QP_0000 = 0x00, DPP_QP_1111 = 0x55, DPP_QP_2222 = 0xAA, DPP_QP
 // merge my ascending list with the partner lane's: afterwards both lanes hold the K smallest of the 2K values, ascending
 template <int K, int CTRL>
 __device__ inline void quad_merge_sorted(float (&l)[K]) {
-  float c[K];
 #pragma unroll
-  for (int j = 0; j < K; ++j) c[j] = fminf(l[j], dpp_f32<CTRL>(l[K - 1 - j]));   // bitonic: lowest K of the union
+  for (int j = 0; j < K / 2; ++j) {                    // bitonic: lowest K of the union, in place (pairs j, K-1-j)
+    const float a = l[j], b = l[K - 1 - j];
+    const float pa = dpp_f32<CTRL>(b), pb = dpp_f32<CTRL>(a);
+    l[j] = fminf(a, pa); l[K - 1 - j] = fminf(b, pb);
+  }
 #pragma unroll
   for (int d = K / 2; d >= 1; d >>= 1) {
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      if ((j & d) == 0) { const float lo = fminf(c[j], c[j + d]), hi = fmaxf(c[j], c[j + d]); c[j] = lo; c[j + d] = hi; }
+      if ((j & d) == 0) { const float lo = fminf(l[j], l[j + d]), hi = fmaxf(l[j], l[j + d]); l[j] = lo; l[j + d] = hi; }
     }
   }
-#pragma unroll
-  for (int j = 0; j < K; ++j) l[j] = c[j];
 }
 
 // one LDS-DMA wave-instruction: active lane L copies 16 bytes from its own `g` to `lbase + L` (lbase wave-uniform)
@@ -887,10 +888,9 @@ void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* c
   const uint32_t nb = (uint32_t)gp.nblocks;
 #define PT_TILE_LAUNCH(KK, CAP, TH) \
   hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n)
-  if (small) {
+  if (small && k <= 16) {            // (K = 32 needs more registers than two workgroups per CU leave: large geometry only)
     if (k <= 8) PT_TILE_LAUNCH(8, PT_TILE_CAP_SMALL_8, 512);
-    else if (k <= 16) PT_TILE_LAUNCH(16, PT_TILE_CAP_SMALL_16, 512);
-    else PT_TILE_LAUNCH(32, PT_TILE_CAP_SMALL_16, 512);
+    else PT_TILE_LAUNCH(16, PT_TILE_CAP_SMALL_16, 512);
   } else {
     if (k <= 8) PT_TILE_LAUNCH(8, PT_TILE_CAP_LARGE, 768);
     else if (k <= 16) PT_TILE_LAUNCH(16, PT_TILE_CAP_LARGE, 768);
