@@ -388,8 +388,11 @@ constexpr int FITEMS = 12;      // records a thread keeps in registers: blocks u
 template <class Rec>
 __global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ in, Rec* __restrict__ out, GridParams gp,
                                                        const uint32_t* __restrict__ block_start, uint32_t* cell_start, uint32_t* occupied) {
+  constexpr int FSTAGE = 64 * 1024 / (int)sizeof(Rec);        // records of a block that fit the 64-KB output stage
+  static_assert(FSTAGE <= FWG * FITEMS, "staged blocks are register-resident blocks");
   __shared__ uint32_t cnt[PT_BLOCK_CELLS];
   __shared__ uint32_t wsum[FWG / 64];
+  __shared__ Rec stage[FSTAGE];
   const uint32_t b = blockIdx.x;
   const uint32_t s = block_start[b], e = block_start[b + 1];
   if (s == e) {   // empty block: only the table
@@ -452,7 +455,17 @@ __global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ i
     if (b == gridDim.x - 1 && threadIdx.x == 0) cell_start[(b + 1) * PT_BLOCK_CELLS] = e;
   }
   __syncthreads();
-  if (in_regs) {
+  if (e - s <= (uint32_t)FSTAGE) {
+    // usual case: the sorted block is assembled in LDS and leaves as full lines (a direct store would be 64 separate
+    // 16-byte requests per wave instruction)
+#pragma unroll
+    for (int j = 0; j < FITEMS; ++j) {
+      const uint32_t i = s + j * FWG + threadIdx.x;
+      if (i < e) stage[atomicAdd(&cnt[lc[j]], 1u)] = r[j];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < e - s; i += FWG) out[s + i] = stage[i];
+  } else if (in_regs) {
 #pragma unroll
     for (int j = 0; j < FITEMS; ++j) {
       const uint32_t i = s + j * FWG + threadIdx.x;
