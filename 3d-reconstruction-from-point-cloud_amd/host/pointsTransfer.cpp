@@ -14,6 +14,7 @@
 //   --k K            neighbours per vertex, default 20            --blend mean|invd2   default mean
 //   --out FILE       default transfer.ply                          --device D           default 0
 //   --neighbors FILE also dump the neighbour indices (binary u32[M][K])
+//   --ply-threads T  parser threads for the two input files (default 0 = one per hardware thread; host/ply_fast.h)
 // There is no CPU path: without a usable GPU the tool reports the error and exits non-zero.
 #include <chrono>
 #include <cstdio>
@@ -25,7 +26,7 @@
 #include <vector>
 
 #include "Point.h"
-#include "ply_io.h"
+#include "ply_fast.h"
 #include "pt_api.h"
 
 namespace {
@@ -53,7 +54,7 @@ int main(int argc, char** argv) {
     return 0;
   }
   const std::string pc_file_name = argv[1], mesh_file_name = argv[2];
-  int K = 20, device = 0, mode = PT_BLEND_MEAN;
+  int K = 20, device = 0, mode = PT_BLEND_MEAN, ply_threads = 0;
   std::string out_name = "transfer.ply", nbr_name;
   for (int i = 3; i < argc; ++i) {
     const std::string a = argv[i];
@@ -62,6 +63,7 @@ int main(int argc, char** argv) {
     else if (a == "--device") device = std::atoi(val());
     else if (a == "--out") out_name = val();
     else if (a == "--neighbors") nbr_name = val();
+    else if (a == "--ply-threads") ply_threads = std::max(0, std::atoi(val()));
     else if (a == "--blend") mode = std::string(val()) == "invd2" ? PT_BLEND_INV_D2 : PT_BLEND_MEAN;
     else { std::cerr << "unknown option " << a << std::endl; return 2; }
   }
@@ -70,9 +72,9 @@ int main(int argc, char** argv) {
   const auto t_total = clk::now();
   auto t_task = clk::now();
 
-  std::vector<Point> points;
+  ply::RecordBuffer points;
   long point_count = 0;
-  if (!ply::read_cloud(pc_file_name, points, point_count)) {
+  if (!ply::read_cloud_fast(pc_file_name, points, point_count, ply_threads)) {
     std::cerr << "Cannot read or find point cloud file: " << pc_file_name << std::endl;
     return 0;   // the reference returns 0 here (:140)
   }
@@ -92,8 +94,8 @@ int main(int argc, char** argv) {
   std::cout << "Built Kd tree in: " << since(t_task) << " seconds" << std::endl;   // the line's wording is the contract
   t_task = clk::now();
 
-  ply::Mesh mesh;
-  if (!ply::read_mesh(mesh_file_name, mesh)) {
+  ply::FastMesh mesh;
+  if (!ply::read_mesh_fast(mesh_file_name, mesh, ply_threads)) {
     std::cerr << "Cannot read or find mesh file: " << mesh_file_name << std::endl;
     pt_ctx_destroy(ctx);
     return 0;   // the reference returns 0 here (:272)

@@ -51,10 +51,11 @@ def test_contract_headers_selftest():
 
 
 def test_ply_reader_under_sanitizers(tmp_path):
-    """host/ply_io.h (the reader behind the CLI) on the reference's grammar and on malformed files, built with
-    AddressSanitizer + UBSan (CPU only: sanitizers are not available on the GPU pool)."""
+    """host/ply_io.h (serial reader) on the reference's grammar and on malformed files, and host/ply_fast.h (the parallel
+    reader behind the CLI) against it at several thread counts -- built with AddressSanitizer + UBSan (CPU only:
+    sanitizers are not available on the GPU pool)."""
     exe = str(tmp_path / "ply_selftest")
-    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-pthread",
                            "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(PKG, "host", "ply_selftest.cpp")])
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0 and "ply selftest ok" in r.stdout, r.stdout + r.stderr
