@@ -292,7 +292,7 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     // targets only need to be grouped by block (tile kernel) -- the cell-level pass is skipped
     const RecF* tsorted = pt_launch_grid_sort<float, RecF>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecF*)c->trec.p, (RecF*)c->trec_tmp.p, nullptr, c->ttb, false, c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    if (c->tile && !bound2_dev && m && k <= 24) {     // beyond k = 24 a region that holds ring 1 no longer fits LDS
+    if (c->tile && !bound2_dev && m && k <= PT_TILE_MAX_K) {
       // regions (10^3 cells) that fit the small capacity with headroom run the two-workgroups-per-CU geometry
       const double cells = (double)c->gp.dim[0] * c->gp.dim[1] * c->gp.dim[2];
       const int tile_small = c->tile == 2 || (c->tile == 1 && (double)c->n / cells * 1000.0 * 1.05 <= (double)(k <= 8 ? PT_TILE_CAP_SMALL_8 : PT_TILE_CAP_SMALL_16));
@@ -329,7 +329,7 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     c->st.ms_query = b;
     c->st.ms_kernel[6] = a;
     c->st.ms_kernel[7] = b;
-    c->st.n_leftover = (c->tile && !bound2_dev && m && k <= 24 && ttype == PT_F32) ? c->h_counter[4] : 0;
+    c->st.n_leftover = (c->tile && !bound2_dev && m && k <= PT_TILE_MAX_K && ttype == PT_F32) ? c->h_counter[4] : 0;
   }
   return PT_OK;
 }
@@ -427,7 +427,8 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
     // (expected k-th distance ~0.8 cell sides), and a 10^3-cell region must fit the tile kernel's LDS budget
     const int k = (int)value;
     if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k_hint out of range");
-    c->rho = k <= 8 ? 4.0 : (k <= 16 ? 6.0 : (k <= 24 ? 8.0 : 12.0));
+    // (k in 25..32: 8.7 keeps the region inside LDS; ring 1 then fails for ~1 target in 8, which the group kernel finishes)
+    c->rho = k <= 8 ? 4.0 : (k <= 16 ? 6.0 : (k <= 24 ? 8.0 : (k <= PT_TILE_MAX_K ? 8.7 : 12.0)));
     return PT_OK;
   }
   if (!strcmp(name, "sync")) { c->sync = value != 0; return PT_OK; }

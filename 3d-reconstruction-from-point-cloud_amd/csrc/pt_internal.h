@@ -52,7 +52,8 @@ void pt_launch_knn(const GridParams& gp, const Rec* src, const uint32_t* cell_st
 // one-thread-per-target tile kernel (fp32 records); leftovers go to todo[*todo_n] and are finished by pt_launch_knn(list=todo)
 // staged-region capacities (records) of the tile kernel's geometries: what is left of 80 KB (two workgroups per CU) or
 // 160 KB (one) after the per-lane queue segments and the cell table
-constexpr int PT_TILE_CAP_SMALL_8 = 4400, PT_TILE_CAP_SMALL_16 = 3888, PT_TILE_CAP_LARGE = 8448;
+constexpr int PT_TILE_CAP_SMALL_8 = 4400, PT_TILE_CAP_SMALL_16 = 3888, PT_TILE_CAP_LARGE = 8448, PT_TILE_CAP_WIDE = 8960;
+constexpr int PT_TILE_MAX_K = 32;      // beyond this the group kernel answers everything
 void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* cell_start, const RecF* tgt, const uint32_t* tblock_start,
                         int k, uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int small, hipStream_t s);
 void pt_launch_merge(const uint32_t* idx_lists, const double* d2_lists, int g, uint32_t m, int k, uint32_t* idx_out,

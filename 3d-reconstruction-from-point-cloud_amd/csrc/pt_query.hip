@@ -390,7 +390,8 @@ constexpr int TILE_R = 10, TILE_CELLS = TILE_R * TILE_R * TILE_R;
 //                 SMALL = 512 threads, ~4460 staged records (70 KB, two workgroups per CU: one stages while the other ranks).
 // queue entries per quad (CAP: room for the k survivors plus whatever else the fp32 bound lets through) and per lane
 // (LCAP: every lane of the quad appends to its own segment, so no atomics and no counters in LDS)
-template <int K> struct TileQ { static constexpr int CAP = K == 8 ? 24 : (K == 16 ? 40 : 48), LCAP = K == 8 ? 8 : 16; };
+// WIDE: k in (24, 32] -- a longer queue for pass 3 (512-thread workgroups: the registers of 12 waves would not hold it)
+template <int K, bool WIDE> struct TileQ { static constexpr int CAP = K == 8 ? 24 : (K == 16 ? 40 : (WIDE ? 64 : 48)), LCAP = K == 8 ? 8 : 16; };
 
 __device__ inline float dist2_f32(float qx, float qy, float qz, const RecF& r) {
   const float dx = qx - r.x, dy = qy - r.y, dz = qz - r.z;
@@ -446,14 +447,14 @@ __device__ inline void glds16(const uint4* g, uint4* lbase) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lbase, 16, 0, 0);
 }
 
-template <int K, int TILE_CAP, int TWG>
+template <int K, int TILE_CAP, int TWG, bool WIDE = false>
 __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(GridParams gp, const RecF* __restrict__ src, const uint32_t* __restrict__ cs,
                                                         const RecF* __restrict__ tgt, const uint32_t* __restrict__ tblock_start, int k,
                                                         uint32_t* __restrict__ out_idx, double* __restrict__ out_d2,
                                                         uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_n) {
   constexpr int NW = TWG / 64;
   constexpr int TILE_QUADS = TWG / 4;
-  constexpr int TILE_QCAP = TileQ<K>::CAP, TILE_LCAP = TileQ<K>::LCAP;
+  constexpr int TILE_QCAP = TileQ<K, WIDE>::CAP, TILE_LCAP = TileQ<K, WIDE>::LCAP;
   __shared__ __attribute__((aligned(16))) RecF lrec[TILE_CAP];
   __shared__ uint16_t lstart[TILE_CELLS + 8];
   __shared__ __attribute__((aligned(16))) uint16_t queue[TWG * (TILE_LCAP + 1)];          // doubles as rowdesc[] during staging
@@ -888,6 +889,11 @@ void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* c
   const uint32_t nb = (uint32_t)gp.nblocks;
 #define PT_TILE_LAUNCH(KK, CAP, TH) \
   hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n)
+  if (k > 24) {                      // wide queue, 512 threads, one workgroup per CU
+    hipLaunchKernelGGL((knn_tile_kernel<32, PT_TILE_CAP_WIDE, 512, true>), dim3(nb), dim3(512), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx,
+                       out_d2, todo, todo_n);
+    return;
+  }
   if (small && k <= 16) {            // (K = 32 needs more registers than two workgroups per CU leave: large geometry only)
     if (k <= 8) PT_TILE_LAUNCH(8, PT_TILE_CAP_SMALL_8, 512);
     else PT_TILE_LAUNCH(16, PT_TILE_CAP_SMALL_16, 512);

@@ -70,7 +70,8 @@ def test_tile_kernel_and_group_kernel_agree(pkg, oracle, k):
         assert p.stats()["n_leftover"] == 0
     _check_exact(got_tile, want, "tile k=%d" % k)
     _check_exact(got_group, want, "group k=%d" % k)
-    assert left < 0.05 * tgt.shape[1], "tile kernel handed over %d of %d targets" % (left, tgt.shape[1])   # (k > 24: not used at all)
+    # k in 25..32 runs at a density where ring 1 is only just enough: up to a quarter may go to the group kernel
+    assert left < (0.05 if k <= 24 else 0.25) * tgt.shape[1], "tile kernel handed over %d of %d targets" % (left, tgt.shape[1])
 
 
 def test_device_generator_matches_oracle(pkg, oracle):
