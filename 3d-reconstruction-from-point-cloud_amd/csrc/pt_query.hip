@@ -9,9 +9,9 @@
 // boxes; ring termination is the same bound applied to the faces of the box already scanned.
 //
 // Two kernels, both exact:
-//   knn_tile_kernel  (second half of this file) fp32 clouds, unbounded queries -- the throughput path.  One workgroup
-//                    per 8^3-cell block stages the 10^3-cell region around it in LDS and ranks it with a DPP quad per
-//                    target: fp32 bound -> queue -> exact fp64 re-rank.  What ring 1 cannot settle goes to a todo list.
+//   knn_tile_kernel  (second half of this file) fp32 clouds, unbounded queries, k <= 32 -- the throughput path.  One
+//                    workgroup per 8^3-cell block stages the 10^3-cell region around it in LDS and ranks it with a DPP quad
+//                    per target: fp32 bound -> queue -> exact fp64 re-rank.  What ring 1 cannot settle goes to a todo list.
 //   knn_kernel       (first half) everything else: fp64 clouds, radius-bounded multi-GPU queries, the todo list.
 //                    8 lanes per target, 8 targets per wave64, 32 per 256-thread workgroup:
 //   - ring 1 (the 3x3x3 cells around the target) is 9 x-rows of 3 cells.  The group's lanes look the rows'
@@ -374,20 +374,25 @@ __global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __res
 //
 // Why a second kernel: the 8-lanes-per-target kernel above is VALU-issue-bound -- every step pays fp64 ranking and
 // cross-lane insertion with 1/8 of the wave doing useful work.  Targets of one block share their 3x3x3 neighbourhoods,
-// so the 10x10x10-cell region around the block is staged ONCE into LDS (coalesced row copies) and ranked from there:
-//   pass 1  each lane of a quad scans its share of the 27 cells (2 rows + 1 cell of the ninth row) in fp32 and keeps
-//           the K smallest VALUES only (v_med3 chain, every lane busy, no payload, no cross-lane traffic); the four
-//           sorted lists are merged with two bitonic DPP steps -> a proven upper bound on the exact k-th squared
-//           distance (see `kth_bound32`);
-//   pass 2  re-scan under that bound (now cells can be pruned), the few candidates within it go to the quad's queue;
-//   pass 3  exact fp64 metric on the queued candidates, ranked under the total order (d2, index) by all-pairs
-//           counting through DPP quad broadcasts; each survivor is written straight to its final slot.
-// Targets that ring 1 cannot settle (k-th neighbour farther than the region guarantees, more near-ties than the queue
-// holds, region larger than the LDS budget) are appended to `todo` and finished by the group kernel.  fp32 records
-// only (the fp32 pre-filter needs exact fp32 inputs).
+// so the 10x10x10-cell region around the block is staged ONCE into LDS and ranked from there:
+//   stage   one thread per region ROW builds the cell table (a row's cells x = 1..8 are eight consecutive keys of one
+//           block); rows go HBM -> LDS by LDS-DMA with wave-uniform addresses, the 200 halo cells through registers;
+//   pass 1  the lanes of a quad walk the 2x2x2 cells nearest to the target interleaved (lane q: records q, q+4, ...)
+//           in fp32 and keep the K smallest VALUES only (v_med3 chain, no payload); one bitonic DPP merge + a max of
+//           mins gives the quad's k-th smallest -> a proven upper bound on the exact k-th squared distance (any set of
+//           >= k candidates bounds it; see `kth_bound32`);
+//   pass 2  ring 1 under that bound, rows and end cells pruned in fp32; what is within the bound is appended, branch-
+//           free, to the lane's own queue segment (no atomics);
+//   pass 3  exact fp64 metric on the queued candidates, ranked by all-pairs counting through DPP quad broadcasts
+//           (distance only; ranks that do not add up reveal equal distances and the quad recounts under (d2, index));
+//           each survivor is written straight to its final slot.
+// Targets that ring 1 cannot settle (k-th neighbour farther than the region guarantees, more candidates under the bound
+// than the queue holds, region larger than the LDS budget) are appended to `todo` and finished by the group kernel.
+// fp32 records only (the fp32 pre-filter needs exact fp32 inputs).
 constexpr int TILE_R = 10, TILE_CELLS = TILE_R * TILE_R * TILE_R;
-// Two geometries: LARGE = 768 threads, 8448 staged records (132 KB, one workgroup per CU) for rho ~ 6-8;
-//                 SMALL = 512 threads, ~4460 staged records (70 KB, two workgroups per CU: one stages while the other ranks).
+// Geometries: LARGE = 768 threads, 8448 staged records (132 KB, one workgroup per CU) for rho ~ 6-8;
+//             SMALL = 512 threads, 4400 / 3888 staged records (two 80-KB workgroups per CU: one stages while the other ranks);
+//             WIDE  = 512 threads, 8960 staged records, 64-entry queue, one per CU: k in 25..32.
 // queue entries per quad (CAP: room for the k survivors plus whatever else the fp32 bound lets through) and per lane
 // (LCAP: every lane of the quad appends to its own segment, so no atomics and no counters in LDS)
 // WIDE: k in (24, 32] -- a longer queue for pass 3 (512-thread workgroups: the registers of 12 waves would not hold it)
