@@ -274,8 +274,12 @@ int copy_in(pt_ctx* c, void* dst, const void* src, size_t bytes, int on_device) 
   return PT_OK;
 }
 
+// optional second half of a query: blend the neighbours' attributes (fused into the tile kernel where that runs)
+struct BlendReq { int mode; float* rgb_out; float* nrm_out; };
+
 // sort the resident targets into cell order and run the k-NN kernel
-int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const double* bound2_dev, uint32_t* idx_dev, double* d2_dev) {
+int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const double* bound2_dev, uint32_t* idx_dev, double* d2_dev,
+              const BlendReq* br = nullptr) {
   if (!c->built) return fail(c, PT_ERR_STATE, "query before build");
   if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k = %d out of range [1, %d]", k, PT_MAX_K);
   if (ttype != c->src_type) return fail(c, PT_ERR_UNSUPPORTED, "target xyz type %d differs from the source cloud's %d", ttype, c->src_type);
@@ -299,13 +303,18 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
       uint32_t* todo_n = (uint32_t*)c->counter.p + 4;
       HIPCHK(c, hipMemsetAsync(todo_n, 0, 4, c->stream));
       pt_launch_knn_tile(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, c->ttb.block_start, k, idx_dev, d2_dev,
-                         (uint32_t*)c->todo.p, todo_n, tile_small, c->stream);
+                         (uint32_t*)c->todo.p, todo_n, tile_small, br ? (const Attr*)c->attr.p : nullptr, (uint32_t)c->n_total, br ? br->mode : 0,
+                         br ? br->rgb_out : nullptr, br ? br->nrm_out : nullptr, c->stream);
       pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, nullptr, idx_dev, d2_dev,
                           (const uint32_t*)c->todo.p, todo_n, c->stream);
+      if (br)   // the targets the tile kernel handed over get their blend from the lists the group kernel just wrote
+        pt_launch_blend_list((const uint32_t*)c->todo.p, todo_n, m, tsorted, idx_dev, d2_dev, k, br->mode, (const Attr*)c->attr.p, (uint32_t)c->n_total,
+                             br->rgb_out, br->nrm_out, c->stream);
       HIPCHK(c, hipMemcpyAsync(c->h_counter + 4, todo_n, 4, hipMemcpyDeviceToHost, c->stream));
     } else {
       pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, bound2_dev, idx_dev, d2_dev,
                           nullptr, nullptr, c->stream);
+      if (br) pt_launch_blend(idx_dev, d2_dev, m, k, br->mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
     }
   } else {
     const double* x = (const double*)txyz;
@@ -313,6 +322,7 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, bound2_dev, idx_dev, d2_dev,
                         nullptr, nullptr, c->stream);
+    if (br) pt_launch_blend(idx_dev, d2_dev, m, k, br->mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
   }
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, hipGetLastError());
@@ -582,6 +592,17 @@ int pt_query_resident(pt_ctx* c, int k, uint32_t* idx_dev, double* d2_dev_or_nul
   if (!c) return PT_ERR_ARG;
   if (c->tgt_type < 0) return fail(c, PT_ERR_STATE, "no resident targets");
   return run_query(c, c->t_xyz.p, c->tgt_type, c->m, k, nullptr, idx_dev, d2_dev_or_null);
+}
+
+int pt_query_blend_resident(pt_ctx* c, int k, int mode, uint32_t* idx_dev, double* d2_dev_or_null, float* rgb_out_dev, float* nrm_out_dev) {
+  if (!c) return PT_ERR_ARG;
+  if (c->tgt_type < 0) return fail(c, PT_ERR_STATE, "no resident targets");
+  if (!c->has_attr) return fail(c, PT_ERR_STATE, "no attribute table resident");
+  if (mode != PT_BLEND_MEAN && mode != PT_BLEND_INV_D2) return fail(c, PT_ERR_ARG, "unknown blend mode %d", mode);
+  if (mode == PT_BLEND_INV_D2 && !d2_dev_or_null) return fail(c, PT_ERR_ARG, "inverse-d2 blend needs d2");
+  const BlendReq br{mode, rgb_out_dev, nrm_out_dev};
+  c->st.ms_blend = 0.f;          // part of ms_query here
+  return run_query(c, c->t_xyz.p, c->tgt_type, c->m, k, nullptr, idx_dev, d2_dev_or_null, &br);
 }
 
 int pt_resident_target_ids(pt_ctx* c, uint32_t* ids_dev) {

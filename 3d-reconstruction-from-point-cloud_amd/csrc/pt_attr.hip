@@ -139,12 +139,9 @@ __global__ __launch_bounds__(WG) void pack_attr_kernel(const uint8_t* __restrict
   attr[i] = a;
 }
 
-// one thread per target: gather the k neighbours' 16-B attribute records and blend them
-__global__ __launch_bounds__(WG) void blend_kernel(const uint32_t* __restrict__ idx, const double* __restrict__ d2, uint32_t m, int k, int mode,
-                                                   const Attr* __restrict__ attr, uint32_t n_attr, float* __restrict__ rgb_out,
-                                                   float* __restrict__ nrm_out) {
-  const uint32_t t = blockIdx.x * WG + threadIdx.x;
-  if (t >= m) return;
+// gather the k neighbours' 16-B attribute records of target row t and blend them
+__device__ inline void blend_one(const uint32_t* __restrict__ idx, const double* __restrict__ d2, uint32_t t, int k, int mode,
+                                 const Attr* __restrict__ attr, uint32_t n_attr, float* __restrict__ rgb_out, float* __restrict__ nrm_out) {
   double wsum = 0.0, c[3] = {0, 0, 0}, nn[3] = {0, 0, 0};
   for (int j = 0; j < k; ++j) {
     const uint32_t id = idx[(size_t)t * k + j];
@@ -164,6 +161,25 @@ __global__ __launch_bounds__(WG) void blend_kernel(const uint32_t* __restrict__ 
   }
   if (rgb_out) { rgb_out[3 * (size_t)t] = (float)c[0]; rgb_out[3 * (size_t)t + 1] = (float)c[1]; rgb_out[3 * (size_t)t + 2] = (float)c[2]; }
   if (nrm_out) { nrm_out[3 * (size_t)t] = (float)nn[0]; nrm_out[3 * (size_t)t + 1] = (float)nn[1]; nrm_out[3 * (size_t)t + 2] = (float)nn[2]; }
+}
+
+// one thread per target
+__global__ __launch_bounds__(WG) void blend_kernel(const uint32_t* __restrict__ idx, const double* __restrict__ d2, uint32_t m, int k, int mode,
+                                                   const Attr* __restrict__ attr, uint32_t n_attr, float* __restrict__ rgb_out,
+                                                   float* __restrict__ nrm_out) {
+  const uint32_t t = blockIdx.x * WG + threadIdx.x;
+  if (t >= m) return;
+  blend_one(idx, d2, t, k, mode, attr, n_attr, rgb_out, nrm_out);
+}
+
+// the same for the targets on a list of positions in the sorted target array (what the tile kernel left to the group kernel)
+__global__ __launch_bounds__(WG) void blend_list_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_n,
+                                                        const RecF* __restrict__ tgt, const uint32_t* __restrict__ idx, const double* __restrict__ d2,
+                                                        int k, int mode, const Attr* __restrict__ attr, uint32_t n_attr, float* __restrict__ rgb_out,
+                                                        float* __restrict__ nrm_out) {
+  const uint32_t i = blockIdx.x * WG + threadIdx.x;
+  if (i >= *list_n) return;
+  blend_one(idx, d2, tgt[list[i]].id, k, mode, attr, n_attr, rgb_out, nrm_out);
 }
 
 // cyclic Jacobi on a symmetric 3x3 (fp64), same sweep order as the oracle
@@ -322,6 +338,11 @@ void pt_launch_blend(const uint32_t* idx, const double* d2, uint32_t m, int k, i
                      float* nrm_out, hipStream_t s) {
   if (!m) return;
   hipLaunchKernelGGL(blend_kernel, grid_for(m), dim3(WG), 0, s, idx, d2, m, k, mode, attr, n_attr, rgb_out, nrm_out);
+}
+void pt_launch_blend_list(const uint32_t* list, const uint32_t* list_n, uint32_t m_max, const RecF* tgt, const uint32_t* idx, const double* d2, int k,
+                          int mode, const Attr* attr, uint32_t n_attr, float* rgb_out, float* nrm_out, hipStream_t s) {
+  if (!m_max) return;
+  hipLaunchKernelGGL(blend_list_kernel, grid_for(m_max), dim3(WG), 0, s, list, list_n, tgt, idx, d2, k, mode, attr, n_attr, rgb_out, nrm_out);
 }
 template <class T>
 void pt_launch_pca(const uint32_t* idx, uint32_t m, int k, const T* x, const T* y, const T* z, uint32_t n, const Attr* attr, float* nrm_out,

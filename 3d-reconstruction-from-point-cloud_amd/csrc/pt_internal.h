@@ -55,7 +55,8 @@ void pt_launch_knn(const GridParams& gp, const Rec* src, const uint32_t* cell_st
 constexpr int PT_TILE_CAP_SMALL_8 = 4400, PT_TILE_CAP_SMALL_16 = 3888, PT_TILE_CAP_LARGE = 8448, PT_TILE_CAP_WIDE = 8960;
 constexpr int PT_TILE_MAX_K = 32;      // beyond this the group kernel answers everything
 void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* cell_start, const RecF* tgt, const uint32_t* tblock_start,
-                        int k, uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int small, hipStream_t s);
+                        int k, uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int small, const Attr* attr, uint32_t n_attr,
+                        int mode, float* rgb_out, float* nrm_out, hipStream_t s);
 void pt_launch_merge(const uint32_t* idx_lists, const double* d2_lists, int g, uint32_t m, int k, uint32_t* idx_out,
                      double* d2_out, hipStream_t s);
 template <class T>
@@ -75,6 +76,8 @@ void pt_launch_synth_attr(uint64_t seed, uint32_t n_total, Attr* attr, hipStream
 // reference AoS records (80-B stride, device copy) -> planar f64 xyz + attribute table
 void pt_launch_aos_split(const void* aos, uint32_t n, double* x, double* y, double* z, Attr* attr, hipStream_t s);
 void pt_launch_pack_attr(const uint8_t* rgb, const float* nrm, uint32_t n, Attr* attr, hipStream_t s);
+void pt_launch_blend_list(const uint32_t* list, const uint32_t* list_n, uint32_t m_max, const RecF* tgt, const uint32_t* idx, const double* d2, int k,
+                          int mode, const Attr* attr, uint32_t n_attr, float* rgb_out, float* nrm_out, hipStream_t s);
 void pt_launch_blend(const uint32_t* idx, const double* d2, uint32_t m, int k, int mode, const Attr* attr, uint32_t n_attr,
                      float* rgb_out, float* nrm_out, hipStream_t s);
 template <class T>

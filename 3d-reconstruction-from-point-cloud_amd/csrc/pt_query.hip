@@ -452,11 +452,14 @@ __device__ inline void glds16(const uint4* g, uint4* lbase) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lbase, 16, 0, 0);
 }
 
-template <int K, int TILE_CAP, int TWG, bool WIDE = false>
+// attribute blend fused into the tile kernel (BLEND): the table, its length, the mode and the two outputs
+struct TileBlend { const Attr* attr; uint32_t n_attr; int mode; float* rgb_out; float* nrm_out; };
+
+template <int K, int TILE_CAP, int TWG, bool WIDE = false, bool BLEND = false>
 __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(GridParams gp, const RecF* __restrict__ src, const uint32_t* __restrict__ cs,
                                                         const RecF* __restrict__ tgt, const uint32_t* __restrict__ tblock_start, int k,
                                                         uint32_t* __restrict__ out_idx, double* __restrict__ out_d2,
-                                                        uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_n) {
+                                                        uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_n, TileBlend bl) {
   constexpr int NW = TWG / 64;
   constexpr int TILE_QUADS = TWG / 4;
   constexpr int TILE_QCAP = TileQ<K, WIDE>::CAP, TILE_LCAP = TileQ<K, WIDE>::LCAP;
@@ -813,6 +816,34 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
         for (int j = 0; j < TILE_QCAP / 4; ++j)
           if (oi[j] != PT_NOIDX_U && rk[j] < k) { out_idx[row + rk[j]] = oi[j]; if (out_d2) out_d2[row + rk[j]] = od[j]; }
         for (uint32_t sl = nq + ql; sl < (uint32_t)k; sl += 4) { out_idx[row + sl] = PT_NOIDX_U; if (out_d2) out_d2[row + sl] = INFINITY; }
+        if constexpr (BLEND) {
+          // the k neighbours' attribute records are gathered right here (their latency hides under the ranking of the
+          // workgroup's other waves) and blended as pt_attr.hip's blend_kernel does: fp64 sums, then one normalisation
+          double ws = 0.0, c0 = 0.0, c1 = 0.0, c2 = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0;
+#pragma unroll
+          for (int j = 0; j < TILE_QCAP / 4; ++j) {
+            if (oi[j] != PT_NOIDX_U && rk[j] < k && oi[j] < bl.n_attr) {
+              const double w = (bl.mode == 1) ? 1.0 / (od[j] + 1e-12) : 1.0;
+              const Attr a = bl.attr[oi[j]];
+              ws += w;
+              c0 += w * (double)(a.rgba & 0xFFu); c1 += w * (double)((a.rgba >> 8) & 0xFFu); c2 += w * (double)((a.rgba >> 16) & 0xFFu);
+              n0 += w * (double)a.nx; n1 += w * (double)a.ny; n2 += w * (double)a.nz;
+            }
+          }
+          auto quad_sum = [](double v) { v += dpp_f64<DPP_QP_1032>(v); v += dpp_f64<DPP_QP_2301>(v); return v; };
+          ws = quad_sum(ws); c0 = quad_sum(c0); c1 = quad_sum(c1); c2 = quad_sum(c2); n0 = quad_sum(n0); n1 = quad_sum(n1); n2 = quad_sum(n2);
+          if (ws > 0.0) {
+            const double iw = 1.0 / ws;
+            c0 *= iw; c1 *= iw; c2 *= iw; n0 *= iw; n1 *= iw; n2 *= iw;
+            const double len = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+            if (len >= 1e-12) { n0 /= len; n1 /= len; n2 /= len; }
+          }
+          float* o = (ql == 0) ? bl.rgb_out : bl.nrm_out;
+          if (ql < 2 && o) {
+            o[3 * (size_t)tr.id] = (float)(ql == 0 ? c0 : n0); o[3 * (size_t)tr.id + 1] = (float)(ql == 0 ? c1 : n1);
+            o[3 * (size_t)tr.id + 2] = (float)(ql == 0 ? c2 : n2);
+          }
+        }
       } else if (ql == 0) {
         todo[atomicAdd(todo_n, 1u)] = t;
       }
@@ -888,24 +919,30 @@ template void pt_launch_knn<RecD>(const GridParams&, const RecD*, const uint32_t
                                   const uint32_t*, const uint32_t*, hipStream_t);
 
 // tile kernel over all blocks; targets it cannot settle are appended to todo[*todo_n] (todo_n zeroed by the caller).
-// `small` selects the two-workgroups-per-CU geometry (regions of <= PT_TILE_CAP_SMALL_* records).
+// `small` selects the two-workgroups-per-CU geometry (regions of <= PT_TILE_CAP_SMALL_* records).  With `attr` the
+// neighbours' attributes are blended in the same pass (rgb_out / nrm_out rows of the settled targets only).
 void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* cell_start, const RecF* tgt, const uint32_t* tblock_start, int k,
-                        uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int small, hipStream_t s) {
+                        uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int small, const Attr* attr, uint32_t n_attr, int mode,
+                        float* rgb_out, float* nrm_out, hipStream_t s) {
   const uint32_t nb = (uint32_t)gp.nblocks;
-#define PT_TILE_LAUNCH(KK, CAP, TH) \
-  hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, out_d2, todo, todo_n)
-  if (k > 24) {                      // wide queue, 512 threads, one workgroup per CU
-    hipLaunchKernelGGL((knn_tile_kernel<32, PT_TILE_CAP_WIDE, 512, true>), dim3(nb), dim3(512), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx,
-                       out_d2, todo, todo_n);
-    return;
-  }
-  if (small && k <= 16) {            // (K = 32 needs more registers than two workgroups per CU leave: large geometry only)
-    if (k <= 8) PT_TILE_LAUNCH(8, PT_TILE_CAP_SMALL_8, 512);
-    else PT_TILE_LAUNCH(16, PT_TILE_CAP_SMALL_16, 512);
+  const TileBlend bl{attr, n_attr, mode, rgb_out, nrm_out};
+#define PT_TILE_LAUNCH(KK, CAP, TH, WD)                                                                                                          \
+  do {                                                                                                                                           \
+    if (attr)                                                                                                                                    \
+      hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH, WD, true>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, \
+                         out_d2, todo, todo_n, bl);                                                                                              \
+    else                                                                                                                                         \
+      hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH, WD, false>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k,         \
+                         out_idx, out_d2, todo, todo_n, bl);                                                                                     \
+  } while (0)
+  if (k > 24) PT_TILE_LAUNCH(32, PT_TILE_CAP_WIDE, 512, true);      // wide queue, 512 threads, one workgroup per CU
+  else if (small && k <= 16) {       // (K = 32 needs more registers than two workgroups per CU leave: large geometry only)
+    if (k <= 8) PT_TILE_LAUNCH(8, PT_TILE_CAP_SMALL_8, 512, false);
+    else PT_TILE_LAUNCH(16, PT_TILE_CAP_SMALL_16, 512, false);
   } else {
-    if (k <= 8) PT_TILE_LAUNCH(8, PT_TILE_CAP_LARGE, 768);
-    else if (k <= 16) PT_TILE_LAUNCH(16, PT_TILE_CAP_LARGE, 768);
-    else PT_TILE_LAUNCH(32, PT_TILE_CAP_LARGE, 768);
+    if (k <= 8) PT_TILE_LAUNCH(8, PT_TILE_CAP_LARGE, 768, false);
+    else if (k <= 16) PT_TILE_LAUNCH(16, PT_TILE_CAP_LARGE, 768, false);
+    else PT_TILE_LAUNCH(32, PT_TILE_CAP_LARGE, 768, false);
   }
 #undef PT_TILE_LAUNCH
 }

@@ -128,9 +128,11 @@ def _f64_to_idx(v):
     return torch.where(u >= 2**31, u - 2**32, u).to(torch.int32)          # back to the u32 bit pattern
 
 
-def exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds):
+def exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds, on_changed=None):
     """Complete the home-slab answers (idx int32 [m,k] holding u32 bit patterns, d2 f64 [m,k], updated IN PLACE)
     with the candidates of the other slabs.  xyz: [3,m] planar coordinates of this rank's targets.
+    on_changed(rows): called with the local rows whose lists were merged with foreign candidates (anything derived from
+    the home-slab lists of those rows -- a fused blend -- has to be redone for them).
     Returns counters: targets sent out, foreign targets answered, bytes all-gathered per rank."""
     G, me = comm.world, comm.rank
     stats = {"crossing": 0, "answered": 0, "bytes_gathered": 0}
@@ -192,4 +194,6 @@ def exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds):
     mi, md = engine.merge(li, ld)
     idx[sel] = mi
     d2[sel] = md
+    if on_changed is not None:
+        on_changed(sel)
     return stats

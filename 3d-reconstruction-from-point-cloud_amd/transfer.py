@@ -170,6 +170,11 @@ class PointsTransfer:
         self._adopt_torch_stream()
         self._chk(self._L.pt_query_resident(self._h, k, _ptr(idx_dev), _ptr(d2_dev)))
 
+    def query_blend_resident_dev(self, k, mode, idx_dev, d2_dev, rgb_out_dev, nrm_out_dev):
+        """query_resident_dev + blend_dev in one pass (the tile kernel gathers the attributes as it settles a target)."""
+        self._adopt_torch_stream()
+        self._chk(self._L.pt_query_blend_resident(self._h, k, mode, _ptr(idx_dev), _ptr(d2_dev), _ptr(rgb_out_dev), _ptr(nrm_out_dev)))
+
     def query_dev(self, xyz_dev, xyz_type, m, k, idx_dev, d2_dev=None):
         self._adopt_torch_stream()
         self._chk(self._L.pt_query_soa(self._h, _ptr(xyz_dev), xyz_type, m, k, 1, _ptr(idx_dev), _ptr(d2_dev)))

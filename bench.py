@@ -49,7 +49,8 @@ def kernel_alg_bytes(name, n, m, k, s=12):
         "pass2_scatter": n * 2 * rec,
         "finalize_cellsort": n * 2 * rec,
         "target_sort": m * (s + rec),
-        "knn_query": n * rec + m * rec + m * k * 12,      # scan every source record once, read targets, write idx + d2
+        # scan every source record once, read targets, write idx + d2; fused blend: gather k 16-B attribute records, write rgb + normal
+        "knn_query": n * rec + m * rec + m * k * 12 + m * k * 16 + m * 24,
     }[name]
 
 
@@ -181,15 +182,24 @@ def main():
     pnrm = torch.empty((m_loc, 3), dtype=torch.float32, device=dev) if with_pca else None
 
     kms = [0.0] * 8
-    phase = {"build": 0.0, "target_sort": 0.0, "knn": 0.0, "blend": 0.0}
+    phase = {"build": 0.0, "target_sort": 0.0, "knn_blend_fused": 0.0, "reblend_merged": 0.0}
     xstats = {}
+
+    def reblend(rows):
+        # targets whose neighbour lists were completed by other slabs: their fused blend is redone from the merged lists
+        c = int(rows.numel())
+        if not c:
+            return
+        r2 = torch.empty((c, 3), dtype=torch.float32, device=dev); n2 = torch.empty((c, 3), dtype=torch.float32, device=dev)
+        pt.blend_dev(idx[rows].contiguous(), d2[rows].contiguous(), c, k, pkg.BLEND_MEAN, r2, n2)
+        rgb[rows] = r2; nrm[rows] = n2
 
     def step(record):
         pt.rebuild()
-        pt.query_resident_dev(k, idx, d2)
+        # k-NN and blend in one pass: the tile kernel gathers the attribute records as it settles each target
+        pt.query_blend_resident_dev(k, pkg.BLEND_MEAN, idx, d2, rgb, nrm)
         st = pt.stats() if record else None       # HIP-event times of the build + home search, on the stream they ran on
-        xs = sharding.exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds)
-        pt.blend_dev(idx, d2, m_loc, k, pkg.BLEND_MEAN, rgb, nrm)
+        xs = sharding.exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds, on_changed=reblend)
         if with_pca:
             pt.pca_normals_dev(idx, m_loc, k, pnrm)     # BASELINE config 3: PCA normal estimation from the neighbours
         if record:
@@ -198,7 +208,7 @@ def main():
             for i in range(8):
                 kms[i] += st["ms_kernel"][i]
             phase["build"] += st["ms_build"]; phase["target_sort"] += st["ms_sort_targets"]
-            phase["knn"] += st["ms_query"]; phase["blend"] += pt.stats()["ms_blend"]
+            phase["knn_blend_fused"] += st["ms_query"]; phase["reblend_merged"] += pt.stats()["ms_blend"]
             xstats.update(xs)
             xstats["tile_leftover"] = st["n_leftover"]
 
@@ -237,7 +247,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d-point source / %d targets / k=%d, %s %s xyz in the unit cube, generator seed 0x%X"
                                    % (args.workload, n_total, m_total, k, dist_name, type_name, seed),
-                       "step": "grid build + target binning + k-NN + slab exchange/merge + mean blend%s, inputs resident in HBM"
+                       "step": "grid build + target binning + k-NN with fused mean blend + slab exchange/merge%s, inputs resident in HBM"
                                % (" + PCA normals" if with_pca else ""),
                        "parallelism": "slab%d" % world if world > 1 else "single", "backend": args.backend if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -141,6 +141,14 @@ int  pt_targets_synth(pt_ctx*, uint64_t m_total, uint64_t seed, int dist, int xy
 uint64_t pt_num_targets(pt_ctx*);
 /* Query the resident targets; idx/d2 are DEVICE buffers of m*k entries (d2 may be NULL). */
 int  pt_query_resident(pt_ctx*, int k, uint32_t* idx_dev, double* d2_dev_or_null);
+/* pt_query_resident and pt_blend_dev in ONE pass over the resident targets (north_star's "find the k nearest
+ * and blend colour/normal onto the vertex"): where the LDS tile kernel answers (fp32 clouds, k <= 32) it gathers
+ * the k attribute records of a target as soon as it has ranked them, so the gathers overlap the ranking of other
+ * targets instead of forming a pass of their own.  Same outputs as the two calls; the blend sums the same fp64
+ * terms in a different order (within the 1e-5 tolerance of the path, not bit-identical to pt_blend_dev).
+ * rgb_out_dev / nrm_out_dev: device float[m*3], either may be NULL. */
+int  pt_query_blend_resident(pt_ctx*, int k, int blend_mode, uint32_t* idx_dev, double* d2_dev_or_null,
+                             float* rgb_out_dev, float* nrm_out_dev);
 /* Global index (position in the whole target set) of each resident target, device u32[m]. */
 int  pt_resident_target_ids(pt_ctx*, uint32_t* ids_dev);
 /* Planar xyz (f32 or f64 as generated) of the resident targets, copied to a device buffer. */

@@ -506,3 +506,47 @@ def test_full_size_c4_two_kernels_agree(pkg):
         torch.cuda.synchronize()
         assert p.stats()["n_leftover"] == 0
         assert torch.equal(gi, idx[sel]) and torch.equal(gd, d2[sel])
+
+
+@pytest.mark.parametrize("k,mode,tile", [(8, 0, 1), (8, 1, 1), (16, 0, 1), (20, 1, 1), (32, 0, 1), (8, 1, 0)])
+def test_fused_query_blend_matches_the_two_calls(pkg, oracle, k, mode, tile):
+    """pt_query_blend_resident = pt_query_resident + pt_blend_dev: identical neighbours and distances, blended attributes
+    within the path's tolerance of the oracle -- on the tile kernel, its hand-over list, and the group kernel alone (tile = 0)."""
+    import torch
+    n, m, seed = 300000, 20000, 0xB1
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.set_param("tile", tile)
+        p.build_synth(n, seed)
+        p.targets_synth(m, seed)
+        i0 = torch.empty((m, k), dtype=torch.int32, device="cuda"); d0 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        p.query_resident_dev(k, i0, d0)
+        i1 = torch.full((m, k), 7, dtype=torch.int32, device="cuda"); d1 = torch.zeros((m, k), dtype=torch.float64, device="cuda")
+        rgb = torch.full((m, 3), -1.0, dtype=torch.float32, device="cuda"); nrm = torch.full((m, 3), -9.0, dtype=torch.float32, device="cuda")
+        p.query_blend_resident_dev(k, mode, i1, d1, rgb, nrm)
+        torch.cuda.synchronize()
+        left = p.stats()["n_leftover"]
+        assert torch.equal(i0, i1) and torch.equal(d0, d1)
+        if tile:
+            assert 0 < left < m, "the case should exercise both the tile kernel and its hand-over list (left=%d)" % left
+    rc, rn = oracle.blend(i0.cpu().numpy().view(np.uint32), d0.cpu().numpy(), oracle.synth_rgb(seed, n), oracle.synth_nrm(seed, n), mode)
+    assert np.abs(rgb.cpu().numpy() - rc).max() / 255 <= TOL and np.abs(nrm.cpu().numpy() - rn).max() <= TOL
+
+
+def test_fused_query_blend_double_cloud_and_errors(pkg):
+    """fp64 clouds take the unfused route behind the same call (bit-identical to the two calls); inverse-d2 without a
+    d2 buffer is refused."""
+    import torch
+    n, m, k, seed = 40000, 3000, 8, 0xD0
+    with pkg.PointsTransfer(device=0) as p:
+        p.build_synth(n, seed, xyz_type=pkg.F64)
+        p.targets_synth(m, seed, xyz_type=pkg.F64)
+        i0 = torch.empty((m, k), dtype=torch.int32, device="cuda"); d0 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        r0 = torch.empty((m, 3), dtype=torch.float32, device="cuda"); n0 = torch.empty((m, 3), dtype=torch.float32, device="cuda")
+        p.query_resident_dev(k, i0, d0)
+        p.blend_dev(i0, d0, m, k, pkg.BLEND_INV_D2, r0, n0)
+        i1 = torch.empty_like(i0); d1 = torch.empty_like(d0); r1 = torch.empty_like(r0); n1 = torch.empty_like(n0)
+        p.query_blend_resident_dev(k, pkg.BLEND_INV_D2, i1, d1, r1, n1)
+        torch.cuda.synchronize()
+        assert torch.equal(i0, i1) and torch.equal(d0, d1) and torch.equal(r0, r1) and torch.equal(n0, n1)
+        with pytest.raises(Exception):
+            p.query_blend_resident_dev(k, pkg.BLEND_INV_D2, i1, None, r1, n1)
