@@ -147,7 +147,7 @@ __device__ inline void blend_one(const uint32_t* __restrict__ idx, const double*
     const uint32_t id = idx[(size_t)t * k + j];
     if (id == PT_NOIDX_U || id >= n_attr) continue;
     const double w = (mode == 1) ? 1.0 / (d2[(size_t)t * k + j] + 1e-12) : 1.0;
-    const Attr a = attr[id];
+    const Attr a = pt_gather_attr(attr, id);
     wsum += w;
     c[0] += w * (double)(a.rgba & 0xFFu); c[1] += w * (double)((a.rgba >> 8) & 0xFFu); c[2] += w * (double)((a.rgba >> 16) & 0xFFu);
     nn[0] += w * (double)a.nx; nn[1] += w * (double)a.ny; nn[2] += w * (double)a.nz;

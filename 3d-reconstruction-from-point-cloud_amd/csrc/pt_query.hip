@@ -824,7 +824,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
           for (int j = 0; j < TILE_QCAP / 4; ++j) {
             if (oi[j] != PT_NOIDX_U && rk[j] < k && oi[j] < bl.n_attr) {
               const double w = (bl.mode == 1) ? 1.0 / (od[j] + 1e-12) : 1.0;
-              const Attr a = bl.attr[oi[j]];
+              const Attr a = pt_gather_attr(bl.attr, oi[j]);
               ws += w;
               c0 += w * (double)(a.rgba & 0xFFu); c1 += w * (double)((a.rgba >> 8) & 0xFFu); c2 += w * (double)((a.rgba >> 16) & 0xFFu);
               n0 += w * (double)a.nx; n1 += w * (double)a.ny; n2 += w * (double)a.nz;
