@@ -260,8 +260,14 @@ int pto_knn_bruteforce(const double* src, uint64_t n, const uint32_t* gidx /* ma
 /*   query: pointsTransfer.cpp:474-478 + SURVEY.md 3.2: root bound            */
 /*          Distance.h:27-57, incremental bound Distance.h:92-95, leaf metric */
 /*          Distance.h:6-11.  Far-subtree pruning uses `new_rd > worst` (not   */
-/*          CGAL's `>=`) so that equal-distance, lower-index points are found: */
-/*          the result is exactly the (d2, idx) total order of (i).           */
+/*          CGAL's `>=`) so that equal-distance, lower-index points are found, */
+/*          and takes the incremental bound with a 1e-10 relative margin: the  */
+/*          running sum rd + new^2 - old^2 is rounded at every level and can   */
+/*          end an ulp ABOVE the exact bound, which on lattice data (exact     */
+/*          ties) pruned subtrees holding a tied, lower-index point (found by  */
+/*          tests/test_gpu_stress.py against the brute force (i); CGAL's own   */
+/*          search has the same rounding, its tie order is unspecified).  The  */
+/*          result is exactly the (d2, idx) total order of (i).               */
 /* ------------------------------------------------------------------------- */
 #define PTO_BUCKET 10
 typedef struct {
@@ -379,7 +385,7 @@ static void kd_search_rec(kdsearch_t* s, int32_t ni, double rd) {
   kd_search_rec(s, nearc, rd);
   const double old_off = s->dists[cd];
   const double new_rd = rd + new_off * new_off - old_off * old_off;           /* Distance.h:92-95 */
-  if (s->cnt < s->k || !(new_rd > s->heap[0].d)) {                            /* visit on <=: total order */
+  if (s->cnt < s->k || !(new_rd * (1.0 - 1e-10) > s->heap[0].d)) {            /* visit on <= (with rounding margin): total order */
     s->dists[cd] = new_off;
     kd_search_rec(s, farc, new_rd);
     s->dists[cd] = old_off;

@@ -1,0 +1,61 @@
+"""Randomised differential test of the HIP k-NN path against the CPU oracle: many small configurations drawn from the
+corners the kernels branch on (densities that overflow the LDS tile, rows longer than one DMA, exact ties on a lattice,
+sheets and lines, targets far outside the cloud, k above the point count, every tile geometry).  PT_STRESS_CASES sets the
+number of cases (default 24; a longer run is a one-off, e.g. PT_STRESS_CASES=400)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(rng, kind, n):
+    if kind == "uniform":
+        return rng.random((3, n), dtype=np.float32)
+    if kind == "lattice":                      # exact distance ties everywhere
+        g = int(rng.integers(3, 40))
+        return (rng.integers(0, g, size=(3, n)).astype(np.float32) / np.float32(g))
+    if kind == "blobs":                        # dense clumps in a sparse background: overflowing tiles, long rows and cells
+        c = rng.random((3, int(rng.integers(1, 6))), dtype=np.float32)
+        s = np.float32(10.0 ** rng.uniform(-4, -1.5))
+        p = c[:, rng.integers(0, c.shape[1], size=n)] + s * rng.standard_normal((3, n)).astype(np.float32)
+        bg = rng.random((3, n), dtype=np.float32)
+        keep = rng.random(n) < 0.85
+        return np.where(keep, p, bg).astype(np.float32)
+    if kind == "sheet":
+        p = rng.random((3, n), dtype=np.float32)
+        p[int(rng.integers(0, 3))] = np.float32(0.37) + np.float32(1e-5) * rng.standard_normal(n).astype(np.float32)
+        return p
+    if kind == "line":
+        t = rng.random(n, dtype=np.float32)
+        return np.stack([t, np.float32(0.5) + np.float32(1e-6) * t, np.float32(0.25) * t]).astype(np.float32)
+    raise AssertionError(kind)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("PT_STRESS_CASES", "24"))))
+def test_random_configuration_matches_oracle(pkg, oracle, case):
+    rng = np.random.default_rng(1000 + case)
+    kind = ["uniform", "lattice", "blobs", "sheet", "line"][case % 5]
+    n = int(rng.choice([1, 7, 300, 5000, 60000, 250000]))
+    m = int(rng.choice([0, 1, 33, 2000, 15000]))
+    k = int(rng.choice([1, 2, 5, 8, 9, 16, 17, 20, 24, 25, 32]))
+    rho = rng.choice([0.0, 1.0, 2.5, 6.0, 12.0, 40.0])            # 0: the k_hint policy
+    tile = int(rng.choice([1, 1, 2, 3, 0]))
+    src = _cloud(rng, kind, n)
+    tgt = _cloud(rng, kind, m) if m else np.zeros((3, 0), np.float32)
+    if m:
+        far = rng.random(m) < 0.05                                        # some targets well outside the cloud
+        tgt[:, far] = tgt[:, far] * np.float32(4.0) - np.float32(1.5)
+        near = rng.random(m) < 0.3                                        # and some right on top of source points
+        if n:
+            tgt[:, near] = src[:, rng.integers(0, n, size=int(near.sum()))]
+    kw = dict(k_hint=k) if rho == 0.0 else dict(rho=float(rho))
+    with pkg.PointsTransfer(device=0, **kw) as p:
+        p.set_param("tile", tile)
+        p.build(src)
+        gi, gd = p.query(tgt, k)
+    wi, wd = oracle.KdTree(src).query(tgt, k) if n else (np.full((m, k), 0xFFFFFFFF, np.uint32), np.full((m, k), np.inf))
+    what = "case %d: %s n=%d m=%d k=%d rho=%g tile=%d" % (case, kind, n, m, k, rho, tile)
+    assert np.array_equal(gi, wi), what + ": indices differ in %d rows" % int((gi != wi).any(axis=1).sum())
+    assert np.array_equal(gd, wd), what + ": d2 differ"

@@ -141,3 +141,31 @@ def test_oracle_blend_and_pca(oracle, golden, golden_cases):
     nn, plan = oracle.pca_normals(i16, p)
     want = np.array([-0.1, 0, 1.0]) / np.linalg.norm([-0.1, 0, 1.0])
     assert np.allclose(nn, want, atol=1e-6) and (plan < 1e-12).all()
+
+
+def test_kdtree_exact_ties_at_the_pruning_bound(oracle):
+    """Lattice clouds make the kd-tree's incremental bound EQUAL to the current k-th distance; rounded an ulp high it
+    used to prune a subtree holding a tied point with a lower index (caught by tests/test_gpu_stress.py, case 171: the
+    GPU agreed with the brute force, the kd-tree did not).  The kd-tree restatement must agree with the brute force on
+    such data, far-away targets included."""
+    from test_gpu_stress import _cloud
+    rng = np.random.default_rng(1000 + 171)                      # the generator sequence of that case
+    n = int(rng.choice([1, 7, 300, 5000, 60000, 250000])); m = int(rng.choice([0, 1, 33, 2000, 15000]))
+    k = int(rng.choice([1, 2, 5, 8, 9, 16, 17, 20, 24, 25, 32])); rng.choice([0.0, 1.0, 2.5, 6.0, 12.0, 40.0]); rng.choice([1, 1, 2, 3, 0])
+    assert (n, m, k) == (250000, 2000, 17)
+    src = _cloud(rng, "lattice", n); tgt = _cloud(rng, "lattice", m)
+    far = rng.random(m) < 0.05
+    tgt[:, far] = tgt[:, far] * np.float32(4.0) - np.float32(1.5)
+    sub = tgt[:, far]
+    bi, bd = oracle.knn_bruteforce(src, sub, k)
+    ki, kd = oracle.KdTree(src).query(sub, k)
+    assert np.array_equal(ki, bi) and np.array_equal(kd, bd)
+    # and a few more lattices with far targets
+    rng = np.random.default_rng(1171)
+    for g, n, k in ((28, 60000, 17), (7, 20000, 32), (13, 40000, 8)):
+        src = (rng.integers(0, g, size=(3, n)).astype(np.float32) / np.float32(g))
+        tgt = np.concatenate([np.array([[-0.5, 2.5, 0.5], [-0.5, -0.5, 1.5], [1.5, 0.5, -2.0]], np.float32),
+                              rng.random((3, 100), dtype=np.float32) * 4 - 1.5], axis=1)
+        bi, bd = oracle.knn_bruteforce(src, tgt, k)
+        ki, kd = oracle.KdTree(src).query(tgt, k)
+        assert np.array_equal(ki, bi) and np.array_equal(kd, bd), "lattice %d" % g
