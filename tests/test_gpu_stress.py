@@ -51,11 +51,15 @@ def test_random_configuration_matches_oracle(pkg, oracle, case):
         if n:
             tgt[:, near] = src[:, rng.integers(0, n, size=int(near.sum()))]
     kw = dict(k_hint=k) if rho == 0.0 else dict(rho=float(rho))
+    f64 = rng.random() < 0.15                                             # the double-precision path (group kernel, 32-byte records)
+    if f64:
+        src = src.astype(np.float64) + (rng.random(src.shape) - 0.5) * 1e-9 * (kind != "lattice")
+        tgt = tgt.astype(np.float64)
     with pkg.PointsTransfer(device=0, **kw) as p:
         p.set_param("tile", tile)
-        p.build(src)
-        gi, gd = p.query(tgt, k)
+        p.build(src, xyz_type=pkg.F64 if f64 else None)
+        gi, gd = p.query(tgt, k, xyz_type=pkg.F64 if f64 else None)
     wi, wd = oracle.KdTree(src).query(tgt, k) if n else (np.full((m, k), 0xFFFFFFFF, np.uint32), np.full((m, k), np.inf))
-    what = "case %d: %s n=%d m=%d k=%d rho=%g tile=%d" % (case, kind, n, m, k, rho, tile)
+    what = "case %d: %s n=%d m=%d k=%d rho=%g tile=%d f64=%d" % (case, kind, n, m, k, rho, tile, f64)
     assert np.array_equal(gi, wi), what + ": indices differ in %d rows" % int((gi != wi).any(axis=1).sum())
     assert np.array_equal(gd, wd), what + ": d2 differ"
