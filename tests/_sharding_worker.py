@@ -79,9 +79,17 @@ def main():
     idx = torch.from_numpy(hi.view(np.int32).copy())
     d2 = torch.from_numpy(hd.copy())
     comm = sharding.TorchDistComm()
-    st = sharding.exchange_and_merge(comm, OracleSlabEngine(slab, gidx), torch.from_numpy(my_tgt), idx, d2, k, 0, bounds)
+    before = idx.clone()
+    changed = []
+    st = sharding.exchange_and_merge(comm, OracleSlabEngine(slab, gidx), torch.from_numpy(my_tgt), idx, d2, k, 0, bounds,
+                                     on_changed=lambda rows: changed.append(rows.clone()))
     got_i = idx.numpy().view(np.uint32)
     ok = np.array_equal(got_i, want_i[mine_t]) and np.array_equal(d2.numpy(), want_d[mine_t])
+    # on_changed names every row whose list was touched (what a fused blend has to redo): rows outside it are unchanged
+    touched = torch.zeros(idx.shape[0], dtype=torch.bool)
+    for rows in changed:
+        touched[rows] = True
+    ok = ok and bool((idx[~touched] == before[~touched]).all()) and int(touched.sum()) == st["crossing"]
     # every rank reports; rank 0 aggregates
     flags = [None] * world
     dist.all_gather_object(flags, (bool(ok), len(mine_t), st["crossing"], st["answered"]))
