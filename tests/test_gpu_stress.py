@@ -50,6 +50,9 @@ def test_random_configuration_matches_oracle(pkg, oracle, case):
         near = rng.random(m) < 0.3                                        # and some right on top of source points
         if n:
             tgt[:, near] = src[:, rng.integers(0, n, size=int(near.sum()))]
+    if rng.random() < 0.4:            # clouds far from the origin / tiny / huge: coarse fp32 spacing, many exact ties
+        sc = np.float32(10.0 ** rng.uniform(-4, 4)); off = np.float32(rng.choice([0.0, 1.0, -37.5, 1000.0, 65536.0]) * float(sc))
+        src = (src * sc + off).astype(np.float32); tgt = (tgt * sc + off).astype(np.float32)
     kw = dict(k_hint=k) if rho == 0.0 else dict(rho=float(rho))
     f64 = rng.random() < 0.15                                             # the double-precision path (group kernel, 32-byte records)
     if f64:
