@@ -49,7 +49,7 @@ void pt_launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t*
 template <class Rec>
 void pt_launch_knn(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const Rec* tgt, uint32_t m, int k,
                    const double* bound2, uint32_t* out_idx, double* out_d2, const uint32_t* list, const uint32_t* list_n, hipStream_t s);
-// one-thread-per-target tile kernel (fp32 records); leftovers go to todo[*todo_n] and are finished by pt_launch_knn(list=todo)
+// quad-per-target LDS tile kernel (fp32 records, k <= 32); leftovers go to todo[*todo_n] and are finished by pt_launch_knn(list=todo)
 // staged-region capacities (records) of the tile kernel's geometries: what is left of 80 KB (two workgroups per CU) or
 // 160 KB (one) after the per-lane queue segments and the cell table
 constexpr int PT_TILE_CAP_SMALL_8 = 4400, PT_TILE_CAP_SMALL_16 = 3888, PT_TILE_CAP_LARGE = 8448, PT_TILE_CAP_WIDE = 8960;

@@ -56,7 +56,7 @@ def test_cell_size_does_not_change_results(pkg, oracle, rho):
 
 @pytest.mark.parametrize("k", [1, 8, 13, 16, 20, 32])
 def test_tile_kernel_and_group_kernel_agree(pkg, oracle, k):
-    """The two k-NN kernels (one thread per target over an LDS-staged tile / 8 lanes per target) must give the same
+    """The two k-NN kernels (a DPP quad per target over an LDS-staged tile / 8 lanes per target) must give the same
     bits as each other and as the oracle; the tile kernel may only hand a small share of the targets over."""
     src, tgt = oracle.synth_xyz(21, 0, 400000), oracle.synth_xyz(21, 1, 30000)
     want = oracle.KdTree(src).query(tgt, k)
