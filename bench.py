@@ -68,6 +68,8 @@ def pmc_traffic(kernel, workload, world):
         return None
     with open(path) as f:
         prof = json.load(f)
+    if kernel == "__step__":
+        return prof.get("step", {}).get("hbm_bytes")
     rec = prof["kernels"].get(PMC_KERNEL.get(kernel, ""))
     return rec["hbm_bytes"] if rec else None
 
@@ -254,7 +256,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(KERNEL_NAMES[dom], args.workload, world),
                          "alg_bytes_per_launch": alg, "avg_launch_ms": kavg[dom]},
             "job_roofline": {"alg_bytes_per_step": b_alg_job, "achieved": b_alg_job / (ms_per_step * 1e-3) / 1e9 / world, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s per GPU", "frac": b_alg_job / (ms_per_step * 1e-3) / 1e9 / world / HBM_PEAK_GBS},
+                             "unit": "GB/s per GPU", "frac": b_alg_job / (ms_per_step * 1e-3) / 1e9 / world / HBM_PEAK_GBS,
+                             # HBM bytes every kernel of one step actually moved (same PMC passes, summed over the step's dispatches)
+                             "traffic_per_step": pmc_traffic("__step__", args.workload, world)},
             "kernels_ms": dict(zip(KERNEL_NAMES, [round(v, 4) for v in kavg])),
             "phases_ms": {a: round(b / K, 4) for a, b in phase.items()},
             "rank0": {"n_source": n_loc, "n_target": m_loc, "exchange": xstats},

@@ -18,9 +18,25 @@ def largest(path, counter):
         if v >= best.get(k, -1.0):
             best[k] = v
     return best
+def per_dispatch(path, counter):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            out[int(r["Dispatch_Id"])] = (short(r["Kernel_Name"]), float(r["Counter_Value"]))
+    return out
+def last_step(path, counter):
+    """Sum over the dispatches of the LAST hot-path step of the run: from its bbox_kernel to the end."""
+    d = per_dispatch(path, counter)
+    ids = sorted(d)
+    starts = [i for i, k in enumerate(ids) if d[k][0] == "bbox_kernel"]
+    return sum(d[k][1] for k in ids[starts[-1]:]) if starts else None
 f = largest(sys.argv[1], "FETCH_SIZE"); w = largest(sys.argv[2], "WRITE_SIZE")
 out = {"workload": sys.argv[3] if len(sys.argv) > 3 else "", "kernels": {}}
 for k in f:
     rd = f[k] * 1024 * 2; wr = w.get(k, 0.0) * 1024
     out["kernels"][k] = {"FETCH_SIZE_KB": f[k], "WRITE_SIZE_KB": w.get(k, 0.0), "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr}
+sf, sw = last_step(sys.argv[1], "FETCH_SIZE"), last_step(sys.argv[2], "WRITE_SIZE")
+if sf is not None and sw is not None:
+    out["step"] = {"note": "all dispatches of the last step (rebuild .. blend)", "FETCH_SIZE_KB": sf, "WRITE_SIZE_KB": sw,
+                   "hbm_read_bytes_corrected": sf * 2048, "hbm_write_bytes": sw * 1024, "hbm_bytes": sf * 2048 + sw * 1024}
 json.dump(out, sys.stdout, indent=1)
