@@ -124,7 +124,8 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
                        ((size_t)nblocks + 8) * 3 + ((size_t)nblocks / 2048 + 16);
   const size_t nchunks = pt_sort_num_chunks(npoints, rec_size), nbins1 = nblocks / PT_MACRO_BLOCKS + 1;
   const size_t chunk_words = nblocks > PT_MAXBINS ? (nchunks + 1) * nbins1 + (nchunks / 64 + 2) * nbins1 : 0;
-  RES(c, mem, (words + chunk_words + 16) * sizeof(uint32_t));
+  const size_t bid_words = nblocks > PT_MAXBINS ? ((size_t)npoints + 3) / 2 + 2 : 0;      // u16 per point, two-level sorts only
+  RES(c, mem, (words + chunk_words + bid_words + 16) * sizeof(uint32_t));
   uint32_t* p = (uint32_t*)mem.p;
   tb.counts1 = p; p += small;
   tb.start1 = p; p += small;
@@ -137,7 +138,8 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
   tb.cursor2 = p; p += (size_t)nblocks + 8;
   tb.scan_tmp = p; p += (size_t)nblocks / 2048 + 16;
   tb.chunk_hist = p; p += (nchunks + 1) * nbins1;
-  tb.chunk_gsum = p;
+  tb.chunk_gsum = p; p += (nchunks / 64 + 2) * nbins1;
+  tb.bid = bid_words ? (uint16_t*)p : nullptr;
   tb.occupied = nullptr;
   tb.ev = nullptr;
   return PT_OK;

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(WG) void colapply_kernel(uint32_t* __restrict__ mat
 }
 template <class Loader, int ITEMS, int SW>
 __global__ __launch_bounds__(SW) void scatter_chunk_kernel(Loader in, typename Loader::Rec* __restrict__ out, GridParams gp, BinSpec bs, uint32_t n,
-                                                           int chunk_tiles, const uint32_t* __restrict__ chunk_base) {
+                                                           int chunk_tiles, const uint32_t* __restrict__ chunk_base, uint16_t* __restrict__ bid) {
   using Rec = typename Loader::Rec;
   constexpr uint32_t TILE = SW * ITEMS;
   constexpr int BPT = PT_MAXBINS / SW;
@@ -375,11 +375,44 @@ __global__ __launch_bounds__(SW) void scatter_chunk_kernel(Loader in, typename L
       const uint32_t slot = j * SW + threadIdx.x;
       if (slot < cnt) {
         const Rec v = stage[slot];
-        out[binB[local_bin(bs, block_of_rec(gp, v))] + slot] = v;
+        const uint32_t blk = block_of_rec(gp, v);
+        const uint32_t pos = binB[local_bin(bs, blk)] + slot;
+        out[pos] = v;
+        bid[pos] = (uint16_t)(blk & (PT_MACRO_BLOCKS - 1));   // 2 bytes here save pass 2's histogram a 16-byte read
       }
     }
     __syncthreads();
   }
+}
+
+// pass-2 histogram from the block ids pass 1 left beside the records: same tiling and flush as hist_kernel
+template <int ITEMS>
+__global__ __launch_bounds__(WG) void hist_bid_kernel(const uint16_t* __restrict__ bid, int nbins, const uint32_t* __restrict__ seg_start,
+                                                      const uint32_t* __restrict__ tile_first, int nseg, uint32_t* counts, int tiles_per_wg) {
+  __shared__ uint32_t hist[PT_MACRO_BLOCKS];
+  constexpr uint32_t TILE = WG * ITEMS;
+  int cur_seg = -1;
+  for (int tt = 0; tt < tiles_per_wg; ++tt) {
+    uint32_t seg, s, e;
+    if (!tile_range(seg_start, tile_first, nseg, blockIdx.x * tiles_per_wg + tt, TILE, seg, s, e)) break;
+    if ((int)seg != cur_seg) {
+      __syncthreads();
+      if (cur_seg >= 0)
+        for (int b = threadIdx.x; b < nbins; b += WG) { const uint32_t c = hist[b]; if (c) atomicAdd(&counts[(uint32_t)cur_seg * PT_MACRO_BLOCKS + b], c); }
+      __syncthreads();
+      for (int b = threadIdx.x; b < nbins; b += WG) hist[b] = 0;
+      __syncthreads();
+      cur_seg = (int)seg;
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const uint32_t i = s + j * WG + threadIdx.x;
+      if (i < e) atomicAdd(&hist[bid[i]], 1u);
+    }
+  }
+  __syncthreads();
+  if (cur_seg >= 0)
+    for (int b = threadIdx.x; b < nbins; b += WG) { const uint32_t c = hist[b]; if (c) atomicAdd(&counts[(uint32_t)cur_seg * PT_MACRO_BLOCKS + b], c); }
 }
 
 // ---- finalize: counting sort of one 8x8x8-cell block by local cell, in LDS -------------------------
@@ -587,17 +620,17 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
     hipLaunchKernelGGL(colapply_kernel, dim3(ngroups), dim3(WG), 0, s, tb.chunk_hist, (int)nchunks, (int)nmacro, tb.chunk_gsum, tb.start1);
     if (chunk_tiles % 2 == 0)     // big clouds: 1024-thread workgroups, tiles twice as long -> twice the bytes per bin and tile
       hipLaunchKernelGGL((scatter_chunk_kernel<PlanarLoader<T>, ITEMS_S, 2 * SW>), dim3(nchunks), dim3(2 * SW), 0, s, pl, out_final, gp, b1, n,
-                         chunk_tiles / 2, tb.chunk_hist);
+                         chunk_tiles / 2, tb.chunk_hist, tb.bid);
     else
       hipLaunchKernelGGL((scatter_chunk_kernel<PlanarLoader<T>, ITEMS_S, SW>), dim3(nchunks), dim3(SW), 0, s, pl, out_final, gp, b1, n, chunk_tiles,
-                         tb.chunk_hist);
+                         tb.chunk_hist, tb.bid);
   }
   mark(2);
   RecLoader<Rec> rl{out_final};
   const uint32_t ntiles2 = ntiles + nmacro;   // upper bound: every segment adds at most one partial tile
   if (n) {
     const int tpw = 4;
-    hipLaunchKernelGGL((hist_kernel<RecLoader<Rec>, ITEMS>), dim3((ntiles2 + tpw - 1) / tpw), dim3(WG), 0, s, rl, gp, b2, tb.start1,
+    hipLaunchKernelGGL((hist_bid_kernel<ITEMS>), dim3((ntiles2 + tpw - 1) / tpw), dim3(WG), 0, s, tb.bid, (int)PT_MACRO_BLOCKS, tb.start1,
                        tb.tile_first2, (int)nmacro, tb.block_count, tpw);
   }
   pt_launch_scan_u32(tb.block_count, tb.block_start, nblocks + 1, tb.scan_tmp, s);

@@ -19,6 +19,7 @@ struct SortTables {
   uint32_t* chunk_hist;  // [nchunks][nbins1]   per-chunk pass-1 histograms, then per-chunk bin cursors
   uint32_t* chunk_gsum;  // [ceil(nchunks/64)][nbins1]
   uint32_t* occupied;    // optional [nblocks]: non-empty cells of every block, written by finalize (may alias block_count)
+  uint16_t* bid;         // [npoints] (two-level sorts): block-in-macro of every record as pass 1 placed it -- what pass 2's histogram reads
   hipEvent_t* ev;        // optional [6]: start, after hist1, scatter1, hist2+scan, scatter2, finalize (null = no timing)
 };
 
