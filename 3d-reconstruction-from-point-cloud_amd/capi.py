@@ -35,7 +35,7 @@ class Stats(C.Structure):
         ("grid_dim", C.c_int32 * 3), ("n_levels", C.c_int32),
         ("cell_size", C.c_double), ("n_cells", C.c_uint64), ("device_bytes", C.c_uint64),
         ("ms_kernel", C.c_double * 8), ("n_leftover", C.c_uint64), ("rho_occupied", C.c_double),
-        ("n_refine", C.c_int32), ("_pad2", C.c_int32),
+        ("n_refine", C.c_int32), ("bbox_guess", C.c_int32),
     ]
 
 

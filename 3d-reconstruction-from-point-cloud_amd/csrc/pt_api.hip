@@ -48,6 +48,7 @@ struct pt_ctx {
   DevBuf in_xyz, in_gidx, attr, rec, rec_tmp, cell_start;
   DevBuf posattr;              // fp32 clouds: {position, attributes} by original index for the PCA pass, built on first use
   bool has_gidx = false, has_attr = false, built = false, posattr_valid = false;
+  bool bbox_guess_ok = true;   // big clouds: lay the grid out from a sampled bounding box (cleared when a guess failed; reset by an upload)
   GridParams gp{};
   SortTables stb{};
   DevBuf stb_mem;
@@ -177,10 +178,30 @@ void choose_grid(pt_ctx* c, const double mn[3], const double mx[3], double force
 }
 
 template <class T, class Rec>
-int run_source_sort(pt_ctx* c) {
+int run_source_sort(pt_ctx* c, uint64_t* bbox6_verify) {
   const T* x = (const T*)c->in_xyz.p;
   pt_launch_grid_sort<T, Rec>(c->gp, x, x + c->n, x + 2 * c->n, c->has_gidx ? (const uint32_t*)c->in_gidx.p : nullptr, (uint32_t)c->n,
-                              (Rec*)c->rec.p, (Rec*)c->rec_tmp.p, (uint32_t*)c->cell_start.p, c->stb, true, c->stream);
+                              (Rec*)c->rec.p, (Rec*)c->rec_tmp.p, (uint32_t*)c->cell_start.p, c->stb, true, c->stream, bbox6_verify);
+  return PT_OK;
+}
+
+// bounding box of the resident cloud: every point (sample_stride = 1) or every sample_stride-th one
+int source_bbox(pt_ctx* c, uint32_t sample_stride, double (&mn)[3], double (&mx)[3]) {
+  pt_launch_bbox_init((uint64_t*)c->bbox6.p, c->stream);
+  if (c->src_type == PT_F32) {
+    const float* x = (const float*)c->in_xyz.p;
+    if (sample_stride > 1) pt_launch_bbox_sample<float>(x, x + c->n, x + 2 * c->n, (uint32_t)c->n, sample_stride, (uint64_t*)c->bbox6.p, c->stream);
+    else pt_launch_bbox<float>(x, x + c->n, x + 2 * c->n, (uint32_t)c->n, (uint64_t*)c->bbox6.p, c->stream);
+  } else {
+    const double* x = (const double*)c->in_xyz.p;
+    if (sample_stride > 1) pt_launch_bbox_sample<double>(x, x + c->n, x + 2 * c->n, (uint32_t)c->n, sample_stride, (uint64_t*)c->bbox6.p, c->stream);
+    else pt_launch_bbox<double>(x, x + c->n, x + 2 * c->n, (uint32_t)c->n, (uint64_t*)c->bbox6.p, c->stream);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_bbox, c->bbox6.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int a = 0; a < 3; ++a) { mn[a] = pt_bbox_decode(c->h_bbox[a]); mx[a] = pt_bbox_decode(c->h_bbox[3 + a]); }
+  for (int a = 0; a < 3; ++a)
+    if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) return fail(c, PT_ERR_ARG, "source coordinates are not finite");
   return PT_OK;
 }
 
@@ -189,15 +210,16 @@ int rebuild(pt_ctx* c) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  // Big clouds: the grid is laid out from the bounding box of a SAMPLE (every 1024th point), widened by the cells the
+  // 64-cell padding of the grid leaves free anyway (up to 2 % per side), and the first full pass over the coordinates
+  // (pass 1's histogram) reduces the exact box along the way.  If the exact box fits the grid -- it does unless the cloud
+  // has outliers the sample missed -- every point is inside the grid as the search requires and one 12-byte-per-point
+  // pass has been saved; otherwise the build is redone from the exact box and the context stops guessing for this cloud.
+  bool guessed = false;
+  c->st.bbox_guess = 0;
   if (c->n) {
-    pt_launch_bbox_init((uint64_t*)c->bbox6.p, c->stream);
-    if (c->src_type == PT_F32) { const float* x = (const float*)c->in_xyz.p; pt_launch_bbox<float>(x, x + c->n, x + 2 * c->n, (uint32_t)c->n, (uint64_t*)c->bbox6.p, c->stream); }
-    else { const double* x = (const double*)c->in_xyz.p; pt_launch_bbox<double>(x, x + c->n, x + 2 * c->n, (uint32_t)c->n, (uint64_t*)c->bbox6.p, c->stream); }
-    HIPCHK(c, hipMemcpyAsync(c->h_bbox, c->bbox6.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int a = 0; a < 3; ++a) { mn[a] = pt_bbox_decode(c->h_bbox[a]); mx[a] = pt_bbox_decode(c->h_bbox[3 + a]); }
-    for (int a = 0; a < 3; ++a)
-      if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) return fail(c, PT_ERR_ARG, "source coordinates are not finite");
+    guessed = c->bbox_guess_ok && c->n >= (8u << 20);
+    { int r = source_bbox(c, guessed ? 1024u : 1u, mn, mx); if (r != PT_OK) return r; }
   }
   // Grid choice.  The first guess assumes the cloud fills its bounding box; finalize counts the non-empty cells, and when
   // those hold far more than rho points each (surfaces, clusters) the cell size is refined -- at most twice, and never
@@ -208,6 +230,21 @@ int rebuild(pt_ctx* c) {
   c->st.n_refine = 0;
   for (int iter = 0;; ++iter) {
     choose_grid(c, mn, mx, force_h);
+    if (guessed && iter == 0) {           // widen the sampled box into the grid's own padding; no room on some axis: no guess
+      int pad[3];
+      bool room = c->gp.nblocks > PT_MAXBINS;     // (the one-level sort has no chunked pass 1 to verify in)
+      for (int a = 0; a < 3; ++a) {
+        pad[a] = std::min((c->gp.mdim[a] * 64 - c->gp.dim[a]) / 2, std::max(1, c->gp.dim[a] / 50));
+        room = room && pad[a] >= 1;
+      }
+      if (room) {
+        for (int a = 0; a < 3; ++a) { c->gp.bbmin[a] -= pad[a] * c->gp.h; c->gp.dim[a] += 2 * pad[a]; }
+      } else {
+        guessed = false;
+        { int r = source_bbox(c, 1u, mn, mx); if (r != PT_OK) return r; }
+        choose_grid(c, mn, mx, force_h);
+      }
+    }
     nblocks = (uint32_t)c->gp.nblocks;
     ncells = (size_t)nblocks * PT_BLOCK_CELLS;
     RES(c, c->cell_start, (ncells + 1) * sizeof(uint32_t));
@@ -217,7 +254,29 @@ int rebuild(pt_ctx* c) {
     c->stb.ev = c->sev;
     uint32_t* occ = (uint32_t*)c->counter.p + 8;
     c->stb.occupied = c->adaptive ? c->stb.block_count : nullptr;     // block_count is dead once block_start exists
-    if (c->src_type == PT_F32) run_source_sort<float, RecF>(c); else run_source_sort<double, RecD>(c);
+    const bool verify = guessed && iter == 0;
+    if (verify) pt_launch_bbox_init((uint64_t*)c->bbox6.p, c->stream);
+    uint64_t* bv = verify ? (uint64_t*)c->bbox6.p : nullptr;
+    if (c->src_type == PT_F32) run_source_sort<float, RecF>(c, bv); else run_source_sort<double, RecD>(c, bv);
+    if (verify) {
+      HIPCHK(c, hipMemcpyAsync(c->h_bbox, c->bbox6.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      bool inside = true, finite = true;
+      for (int a = 0; a < 3; ++a) {
+        mn[a] = pt_bbox_decode(c->h_bbox[a]); mx[a] = pt_bbox_decode(c->h_bbox[3 + a]);      // exact from here on
+        finite = finite && std::isfinite(mn[a]) && std::isfinite(mx[a]);
+        inside = inside && mn[a] >= c->gp.bbmin[a] && mx[a] <= c->gp.bbmin[a] + c->gp.dim[a] * c->gp.h;
+      }
+      if (!finite) return fail(c, PT_ERR_ARG, "source coordinates are not finite");
+      c->st.bbox_guess = inside ? 1 : -1;
+      if (!inside) {          // the sample missed part of the cloud: start over from the exact box, no more guessing for this cloud
+        c->bbox_guess_ok = false;
+        guessed = false;
+        force_h = 0.0;
+        --iter;
+        continue;
+      }
+    }
     c->st.rho_occupied = 0.0;
     if (!c->adaptive || !c->n) break;
     HIPCHK(c, hipMemsetAsync(occ, 0, 4, c->stream));
@@ -480,7 +539,7 @@ int pt_build_aos(pt_ctx* c, const pt_point* cloud, uint64_t n) {
   { int r = copy_in(c, c->aos_stage.p, cloud, n * sizeof(pt_point), 0); if (r) return r; }
   double* x = (double*)c->in_xyz.p;
   pt_launch_aos_split(c->aos_stage.p, (uint32_t)n, x, x + n, x + 2 * n, (Attr*)c->attr.p, c->stream);
-  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false; c->posattr_valid = false;
+  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true;
   return rebuild(c);
 }
 
@@ -495,7 +554,7 @@ int pt_build_soa_indexed(pt_ctx* c, const void* xyz, int xyz_type, const uint32_
   }
   c->src_type = xyz_type; c->n = n; c->has_gidx = gidx != nullptr; c->built = false;
   if (!gidx) { c->n_total = n; c->has_attr = false; }
-  c->posattr_valid = false;
+  c->posattr_valid = false; c->bbox_guess_ok = true;
   return rebuild(c);
 }
 
@@ -551,7 +610,7 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
   else { double* x = (double*)c->in_xyz.p; pt_launch_synth_xyz<double>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream); }
   RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
   pt_launch_synth_attr(seed, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
-  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false; c->posattr_valid = false;
+  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true;
   return rebuild(c);
 }
 

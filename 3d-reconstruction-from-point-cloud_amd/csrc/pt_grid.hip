@@ -111,6 +111,32 @@ __global__ __launch_bounds__(WG) void bbox_kernel(const T* __restrict__ x, const
     }
   }
 }
+// bounding box of every `stride`-th point (a guess of the cloud's extent from ~1e6 points)
+template <class T>
+__global__ __launch_bounds__(WG) void bbox_sample_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, uint32_t n,
+                                                         uint32_t stride, uint64_t* out6) {
+  double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  const uint64_t i = ((uint64_t)blockIdx.x * WG + threadIdx.x) * stride;
+  if (i < n) {
+    const double v[3] = {(double)x[i], (double)y[i], (double)z[i]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = v[a]; mx[a] = v[a]; }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn[a] = fmin(mn[a], __shfl_xor(mn[a], o)); mx[a] = fmax(mx[a], __shfl_xor(mx[a], o)); }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (mn[a] <= mx[a]) {
+        atomicMin((unsigned long long*)&out6[a], (unsigned long long)enc_f64(mn[a]));
+        atomicMax((unsigned long long*)&out6[3 + a], (unsigned long long)enc_f64(mx[a]));
+      }
+    }
+  }
+}
 __global__ void bbox_init_kernel(uint64_t* out6) {
   if (threadIdx.x < 3) out6[threadIdx.x] = ~0ull;
   else if (threadIdx.x < 6) out6[threadIdx.x] = 0ull;
@@ -280,16 +306,49 @@ __global__ __launch_bounds__(SW) void scatter_kernel(Loader in, typename Loader:
 // ---- pass 1 without atomics: fixed chunks of tiles, per-chunk histograms, column scan, chunk-local cursors ----
 // (with only <= 1024 bins, a global cursor per bin would be hit by every tile of the cloud: at 1e9 points that
 //  serialises ~5e5 reservations per address.  Chunks make the placement deterministic and contention-free.)
+// (bbox6, optional: the exact bounding box of everything read, for a build whose grid was laid out from a SAMPLE of the
+//  cloud -- the first full pass over the coordinates verifies the guess instead of a pass of its own preceding it)
 template <class Loader, int ITEMS>
 __global__ __launch_bounds__(WG) void hist_chunk_kernel(Loader in, GridParams gp, BinSpec bs, uint32_t n, int chunk_tiles,
-                                                        uint32_t* __restrict__ chunk_hist) {
+                                                        uint32_t* __restrict__ chunk_hist, uint64_t* bbox6) {
   __shared__ uint32_t hist[PT_MAXBINS];
   for (int b = threadIdx.x; b < bs.nbins; b += WG) hist[b] = 0;
   __syncthreads();
   const uint64_t span = (uint64_t)chunk_tiles * (WG * ITEMS);
   const uint64_t base = (uint64_t)blockIdx.x * span;
   const uint32_t end = (uint32_t)min((uint64_t)n, base + span);
-  for (uint32_t i = (uint32_t)base + threadIdx.x; i < end; i += WG) atomicAdd(&hist[local_bin(bs, block_of_rec(gp, in.load(i)))], 1u);
+  using CT = decltype(in.load(0).x);                 // min / max in the cloud's own type: exact, and cheap for fp32
+  CT tmn[3] = {(CT)INFINITY, (CT)INFINITY, (CT)INFINITY}, tmx[3] = {(CT)-INFINITY, (CT)-INFINITY, (CT)-INFINITY};
+  for (uint32_t i = (uint32_t)base + threadIdx.x; i < end; i += WG) {
+    const auto r = in.load(i);
+    atomicAdd(&hist[local_bin(bs, block_of_rec(gp, r))], 1u);
+    if (bbox6) {
+      tmn[0] = r.x < tmn[0] ? r.x : tmn[0]; tmx[0] = r.x > tmx[0] ? r.x : tmx[0];
+      tmn[1] = r.y < tmn[1] ? r.y : tmn[1]; tmx[1] = r.y > tmx[1] ? r.y : tmx[1];
+      tmn[2] = r.z < tmn[2] ? r.z : tmn[2]; tmx[2] = r.z > tmx[2] ? r.z : tmx[2];
+    }
+  }
+  if (bbox6) {
+    double mn[3] = {(double)tmn[0], (double)tmn[1], (double)tmn[2]}, mx[3] = {(double)tmx[0], (double)tmx[1], (double)tmx[2]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { mn[a] = fmin(mn[a], __shfl_xor(mn[a], o)); mx[a] = fmax(mx[a], __shfl_xor(mx[a], o)); }
+    }
+    // one set of atomics per WORKGROUP (thousands of waves hitting six addresses serialise: measured +1.2 ms per wave)
+    __shared__ double wbox[WG / 64][6];
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { wbox[threadIdx.x >> 6][a] = mn[a]; wbox[threadIdx.x >> 6][3 + a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      double v = wbox[0][threadIdx.x];
+      for (int w = 1; w < WG / 64; ++w) v = threadIdx.x < 3 ? fmin(v, wbox[w][threadIdx.x]) : fmax(v, wbox[w][threadIdx.x]);
+      if (threadIdx.x < 3) { if (v != INFINITY) atomicMin((unsigned long long*)&bbox6[threadIdx.x], (unsigned long long)enc_f64(v)); }
+      else if (v != -INFINITY) atomicMax((unsigned long long*)&bbox6[threadIdx.x], (unsigned long long)enc_f64(v));
+    }
+  }
   __syncthreads();
   for (int b = threadIdx.x; b < bs.nbins; b += WG) chunk_hist[(size_t)blockIdx.x * bs.nbins + b] = hist[b];
 }
@@ -547,6 +606,14 @@ void pt_launch_bbox(const T* x, const T* y, const T* z, uint32_t n, uint64_t* ou
   const uint32_t g = (uint32_t)std::min<uint64_t>(((uint64_t)n + WG - 1) / WG, 2048);
   hipLaunchKernelGGL(bbox_kernel<T>, dim3(g), dim3(WG), 0, s, x, y, z, n, out6);
 }
+template <class T>
+void pt_launch_bbox_sample(const T* x, const T* y, const T* z, uint32_t n, uint32_t stride, uint64_t* out6, hipStream_t s) {
+  if (!n) return;
+  const uint32_t cnt = (n + stride - 1) / stride;
+  hipLaunchKernelGGL(bbox_sample_kernel<T>, dim3((cnt + WG - 1) / WG), dim3(WG), 0, s, x, y, z, n, stride, out6);
+}
+template void pt_launch_bbox_sample<float>(const float*, const float*, const float*, uint32_t, uint32_t, uint64_t*, hipStream_t);
+template void pt_launch_bbox_sample<double>(const double*, const double*, const double*, uint32_t, uint32_t, uint64_t*, hipStream_t);
 template void pt_launch_bbox<float>(const float*, const float*, const float*, uint32_t, uint64_t*, hipStream_t);
 template void pt_launch_bbox<double>(const double*, const double*, const double*, uint32_t, uint64_t*, hipStream_t);
 double pt_bbox_decode(uint64_t enc) {
@@ -566,7 +633,7 @@ void pt_launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t*
 
 template <class T, class Rec>
 const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* z, const uint32_t* gidx, uint32_t n, Rec* out_final,
-                               Rec* tmp, uint32_t* cell_start, const SortTables& tb, bool do_finalize, hipStream_t s) {
+                               Rec* tmp, uint32_t* cell_start, const SortTables& tb, bool do_finalize, hipStream_t s, uint64_t* bbox6_verify) {
   constexpr int SW = 512;                              // scatter workgroup: 8 waves, 64 KB of staged records, 2 per CU
   constexpr int ITEMS_S = items_for<Rec>();            // records per scatter thread (8 / 4)
   constexpr int ITEMS = ITEMS_S * (SW / WG);           // records per histogram thread (same tile, 256 threads)
@@ -610,7 +677,8 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
   const uint32_t ngroups = (nchunks + COL_GROUP - 1) / COL_GROUP;
   (void)hipMemsetAsync(tb.counts1, 0, sizeof(uint32_t) * (PT_MAXBINS + 1), s);
   if (n) {
-    hipLaunchKernelGGL((hist_chunk_kernel<PlanarLoader<T>, ITEMS>), dim3(nchunks), dim3(WG), 0, s, pl, gp, b1, n, chunk_tiles, tb.chunk_hist);
+    hipLaunchKernelGGL((hist_chunk_kernel<PlanarLoader<T>, ITEMS>), dim3(nchunks), dim3(WG), 0, s, pl, gp, b1, n, chunk_tiles, tb.chunk_hist,
+                       bbox6_verify);
     hipLaunchKernelGGL(colsum_kernel, dim3(ngroups), dim3(WG), 0, s, tb.chunk_hist, (int)nchunks, (int)nmacro, tb.chunk_gsum);
     hipLaunchKernelGGL(colscan_kernel, dim3(1), dim3(WG), 0, s, tb.chunk_gsum, (int)ngroups, (int)nmacro, tb.counts1);
   }
@@ -645,9 +713,9 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
   return do_finalize ? out_final : tmp;
 }
 template const RecF* pt_launch_grid_sort<float, RecF>(const GridParams&, const float*, const float*, const float*, const uint32_t*, uint32_t, RecF*,
-                                                      RecF*, uint32_t*, const SortTables&, bool, hipStream_t);
+                                                      RecF*, uint32_t*, const SortTables&, bool, hipStream_t, uint64_t*);
 template const RecD* pt_launch_grid_sort<double, RecD>(const GridParams&, const double*, const double*, const double*, const uint32_t*, uint32_t,
-                                                       RecD*, RecD*, uint32_t*, const SortTables&, bool, hipStream_t);
+                                                       RecD*, RecD*, uint32_t*, const SortTables&, bool, hipStream_t, uint64_t*);
 void pt_launch_sum_u32(const uint32_t* v, uint32_t n, uint32_t* out, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(sum_u32_kernel, dim3(std::min<uint32_t>((n + WG - 1) / WG, 64)), dim3(WG), 0, s, v, n, out);

@@ -27,6 +27,7 @@ struct SortTables {
 // bbox of planar xyz (T = float/double); out6 = orderable-u64 encoded {min xyz, max xyz}; init first.
 void pt_launch_bbox_init(uint64_t* out6, hipStream_t s);
 template <class T> void pt_launch_bbox(const T* x, const T* y, const T* z, uint32_t n, uint64_t* out6, hipStream_t s);
+template <class T> void pt_launch_bbox_sample(const T* x, const T* y, const T* z, uint32_t n, uint32_t stride, uint64_t* out6, hipStream_t s);
 double pt_bbox_decode(uint64_t enc);
 
 // Sort n points into cell order.  Planar input (x,y,z[,gidx]); `out_final` and `tmp` are record buffers of n entries.
@@ -35,7 +36,8 @@ double pt_bbox_decode(uint64_t enc);
 // kernel needs of the TARGETS.  Returns the buffer that holds the result.  Rec = RecF (T=float) or RecD (T=double).
 template <class T, class Rec>
 const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* z, const uint32_t* gidx, uint32_t n,
-                               Rec* out_final, Rec* tmp, uint32_t* cell_start, const SortTables& tb, bool do_finalize, hipStream_t s);
+                               Rec* out_final, Rec* tmp, uint32_t* cell_start, const SortTables& tb, bool do_finalize, hipStream_t s,
+                               uint64_t* bbox6_verify = nullptr);   // two-level sorts: pass 1's histogram also reduces the exact bbox into it
 void pt_launch_sum_u32(const uint32_t* v, uint32_t n, uint32_t* out, hipStream_t s);   // *out += sum(v[0..n))
 int pt_sort_tile_points(size_t rec_size);
 int pt_sort_chunk_tiles(uint32_t n, size_t rec_size);

@@ -84,7 +84,9 @@ typedef struct pt_stats_t {
   double ms_kernel[8];
   uint64_t n_leftover;      /* targets of the last query that the tile kernel handed to the group kernel */
   double rho_occupied;      /* points per NON-EMPTY cell of the last build (0 when adaptive is off) */
-  int32_t n_refine, _pad2;  /* how many times the last build refined its cell size */
+  int32_t n_refine;         /* how many times the last build refined its cell size */
+  int32_t bbox_guess;       /* last build: 0 the bounding box came from a pass of its own; 1 the grid was laid out from a sampled
+                             * box and pass 1 verified it (big clouds); -1 the sampled box was too small and the build was redone */
 } pt_stats_t;
 
 /* ---- context ------------------------------------------------------------------------ */

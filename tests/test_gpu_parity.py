@@ -550,3 +550,30 @@ def test_fused_query_blend_double_cloud_and_errors(pkg):
         assert torch.equal(i0, i1) and torch.equal(d0, d1) and torch.equal(r0, r1) and torch.equal(n0, n1)
         with pytest.raises(Exception):
             p.query_blend_resident_dev(k, pkg.BLEND_INV_D2, i1, None, r1, n1)
+
+
+def test_sampled_bounding_box_and_its_fallback(pkg, oracle):
+    """Clouds of 8 M points and more lay their grid out from a sampled bounding box that pass 1 verifies.  An outlier the
+    sample misses must send the build back to the exact box -- with the same neighbours either way."""
+    n, m, k, seed = 9_000_000, 3000, 8, 0x5A
+    src = oracle.synth_xyz(seed, 0, n)
+    tgt = oracle.synth_xyz(seed, 1, m)
+    kd = oracle.KdTree(src)
+    with pkg.PointsTransfer(device=0) as p:
+        p.build(src)
+        assert p.stats()["bbox_guess"] == 1
+        got = p.query(tgt, k)
+        _check_exact(got, kd.query(tgt, k), "sampled box accepted")
+        p.rebuild()
+        assert p.stats()["bbox_guess"] == 1
+    out = src.copy()
+    out[:, 12345] = (3.0, -2.0, 7.5)                        # not on the sample's stride
+    tgt2 = np.concatenate([tgt, np.array([[2.9, 0.5], [-1.9, 0.5], [7.4, 0.5]], np.float32)], axis=1)
+    kd2 = oracle.KdTree(out)
+    with pkg.PointsTransfer(device=0) as p:
+        p.build(out)
+        assert p.stats()["bbox_guess"] == -1
+        _check_exact(p.query(tgt2, k), kd2.query(tgt2, k), "sampled box rejected")
+        p.rebuild()
+        assert p.stats()["bbox_guess"] == 0                  # no second guess for this cloud
+        _check_exact(p.query(tgt2, k), kd2.query(tgt2, k), "exact box")
