@@ -48,6 +48,7 @@ struct pt_ctx {
   DevBuf in_xyz, in_gidx, attr, rec, rec_tmp, cell_start;
   DevBuf posattr;              // fp32 clouds: {position, attributes} by original index for the PCA pass, built on first use
   bool has_gidx = false, has_attr = false, built = false, posattr_valid = false;
+  uint64_t guess_min_points = 8u << 20;   // clouds at least this large lay their grid out from a sampled bounding box
   bool bbox_guess_ok = true;   // big clouds: lay the grid out from a sampled bounding box (cleared when a guess failed; reset by an upload)
   GridParams gp{};
   SortTables stb{};
@@ -218,7 +219,7 @@ int rebuild(pt_ctx* c) {
   bool guessed = false;
   c->st.bbox_guess = 0;
   if (c->n) {
-    guessed = c->bbox_guess_ok && c->n >= (8u << 20);
+    guessed = c->bbox_guess_ok && c->n >= c->guess_min_points;
     { int r = source_bbox(c, guessed ? 1024u : 1u, mn, mx); if (r != PT_OK) return r; }
   }
   // Grid choice.  The first guess assumes the cloud fills its bounding box; finalize counts the non-empty cells, and when
@@ -504,7 +505,8 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
   }
   if (!strcmp(name, "sync")) { c->sync = value != 0; return PT_OK; }
   if (!strcmp(name, "adaptive")) { c->adaptive = value != 0; return PT_OK; }
-  if (!strcmp(name, "tile")) { c->tile = (int)value; return PT_OK; }   // 0 group kernel only, 1 auto, 2 small tiles, 3 large tiles
+  if (!strcmp(name, "tile")) { c->tile = (int)value; return PT_OK; }
+  if (!strcmp(name, "guess_min_points")) { c->guess_min_points = value < 1 ? 1 : (uint64_t)value; return PT_OK; }   // sampled-bbox builds from this size up   // 0 group kernel only, 1 auto, 2 small tiles, 3 large tiles
   if (!strcmp(name, "own_stream")) { if (value != 0) c->stream = c->own_stream; return PT_OK; }
   return fail(c, PT_ERR_ARG, "unknown parameter '%s'", name);
 }

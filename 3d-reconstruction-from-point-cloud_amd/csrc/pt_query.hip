@@ -33,6 +33,7 @@ namespace {
 
 constexpr int WG = 256;
 constexpr int GL = 8;   // lanes per target
+constexpr int PT_RING_LIMIT = 8;   // rings walked shell by shell before the group kernel sweeps the blocks instead
 
 __device__ inline bool key_lt(double ad, uint32_t ai, double bd, uint32_t bi) { return ad < bd || (ad == bd && ai < bi); }
 
@@ -342,6 +343,41 @@ __global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __res
     if (covered) break;
     dout = fmax(dout - PT_CELL_EPS, 0.0);
     if (dout * dout * T.h2 > top.lim_d) break;
+    if (r >= PT_RING_LIMIT) {
+      // Far from the points (a stray target, a gap in the cloud): walking ever larger, mostly empty shells costs O(r^2)
+      // per ring.  Sweep the BLOCKS instead -- skip the empty ones, prune the others by their box, scan what is left --
+      // starting the list again so that no point is offered twice.  O(blocks) per such target, exact like the walk.
+      top.init(L, k, bound2 ? bound2[tr.id] : INFINITY);
+      const uint32_t nb = (uint32_t)gp.nblocks;
+      for (uint32_t b0 = 0; b0 < nb; b0 += GL) {
+        const uint32_t b = b0 + (uint32_t)L;             // lane L looks at block b0 + L
+        uint32_t bs_ = 0, be_ = 0;
+        if (b < nb) { bs_ = cs[(size_t)b * PT_BLOCK_CELLS]; be_ = cs[((size_t)b + 1) * PT_BLOCK_CELLS]; }
+        bool want = be_ > bs_;
+        if (want) {
+          const uint32_t macro = b >> 9, m9 = b & 511u;
+          const int bx = (int)(macro % (uint32_t)gp.mdim[0]) * 8 + (int)((m9 & 1u) | ((m9 >> 2) & 2u) | ((m9 >> 4) & 4u));
+          const int by = (int)((macro / (uint32_t)gp.mdim[0]) % (uint32_t)gp.mdim[1]) * 8 + (int)(((m9 >> 1) & 1u) | ((m9 >> 3) & 2u) | ((m9 >> 5) & 4u));
+          const int bz = (int)(macro / (uint32_t)(gp.mdim[0] * gp.mdim[1])) * 8 + (int)(((m9 >> 2) & 1u) | ((m9 >> 4) & 2u) | ((m9 >> 6) & 4u));
+          const double gx = T.gap(0, bx * 8, bx * 8 + 7), gy = T.gap(1, by * 8, by * 8 + 7), gz = T.gap(2, bz * 8, bz * 8 + 7);
+          want = !((gx * gx + gy * gy + gz * gz) * T.h2 > top.lim_d);
+        }
+        uint32_t mask = (uint32_t)((__ballot(want) >> gshift) & 0xFFull);      // the group's eight verdicts
+        while (mask) {                                    // group-uniform
+          const int j = __ffs((int)mask) - 1;
+          mask &= mask - 1;
+          const uint32_t s0 = (uint32_t)__shfl(bs_, gshift + j), e0 = (uint32_t)__shfl(be_, gshift + j);
+          for (uint32_t base = s0; base < e0; base += GL) {
+            const uint32_t p = base + (uint32_t)L;
+            double d = INFINITY;
+            uint32_t id = PT_NOIDX_U;
+            if (p < e0) { const Rec rc = src[p]; d = dist2(T.q, rc); id = rc.id; }
+            top.offer(d, id, gshift);
+          }
+        }
+      }
+      break;
+    }
     const int rr = r + 1;                      // scan the shell box(rr) \ box(rr-1)
     const int x0 = max(c0 - rr, 0), x1 = min(c0 + rr, gp.dim[0] - 1);
     const int y0 = max(c1 - rr, 0), y1 = min(c1 + rr, gp.dim[1] - 1);

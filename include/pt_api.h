@@ -102,7 +102,8 @@ int  pt_set_stream(pt_ctx*, void* hip_stream);
  * the GPU is done, default 1; 0 = _dev calls only enqueue), "adaptive" (1 = refine the cell
  * size when non-empty cells hold far more than rho points, default; needs one host read-back per build), "tile" (0 = group kernel only, 1 = tile kernel +
  * group kernel for its leftovers with the geometry chosen from the cell density (default), 2 / 3 = force the small /
- * large tile geometry). */
+ * large tile geometry), "guess_min_points" (clouds at least this large lay their grid out from the bounding box of a
+ * sample and verify it during the first partition pass instead of spending a pass on the exact box; default 8 Mi). */
 int  pt_set_param(pt_ctx*, const char* name, double value);
 const char* pt_last_error(pt_ctx*);
 int  pt_stats(pt_ctx*, pt_stats_t* out);

@@ -553,27 +553,27 @@ def test_fused_query_blend_double_cloud_and_errors(pkg):
 
 
 def test_sampled_bounding_box_and_its_fallback(pkg, oracle):
-    """Clouds of 8 M points and more lay their grid out from a sampled bounding box that pass 1 verifies.  An outlier the
-    sample misses must send the build back to the exact box -- with the same neighbours either way."""
-    n, m, k, seed = 9_000_000, 3000, 8, 0x5A
+    """Big clouds (>= "guess_min_points", lowered here) lay their grid out from a sampled bounding box that pass 1
+    verifies.  An outlier the sample misses must send the build back to the exact box -- same neighbours either way."""
+    n, m, k, seed = 400_000, 3000, 8, 0x5A
     src = oracle.synth_xyz(seed, 0, n)
     tgt = oracle.synth_xyz(seed, 1, m)
-    kd = oracle.KdTree(src)
-    with pkg.PointsTransfer(device=0) as p:
+    with pkg.PointsTransfer(device=0, rho=0.5) as p:          # rho 0.5: enough blocks for the two-level (chunked) sort
+        p.set_param("guess_min_points", 100000)
         p.build(src)
-        assert p.stats()["bbox_guess"] == 1
-        got = p.query(tgt, k)
-        _check_exact(got, kd.query(tgt, k), "sampled box accepted")
+        assert p.stats()["bbox_guess"] == 1 and p.stats()["n_levels"] == 2
+        _check_exact(p.query(tgt, k), oracle.KdTree(src).query(tgt, k), "sampled box accepted")
         p.rebuild()
         assert p.stats()["bbox_guess"] == 1
     out = src.copy()
     out[:, 12345] = (3.0, -2.0, 7.5)                        # not on the sample's stride
-    tgt2 = np.concatenate([tgt, np.array([[2.9, 0.5], [-1.9, 0.5], [7.4, 0.5]], np.float32)], axis=1)
-    kd2 = oracle.KdTree(out)
-    with pkg.PointsTransfer(device=0) as p:
+    tgt2 = np.concatenate([tgt, np.array([[2.9, 3.0], [-1.9, -2.0], [7.4, 7.5]], np.float32)], axis=1)
+    want = oracle.KdTree(out).query(tgt2, k)
+    with pkg.PointsTransfer(device=0, rho=0.5) as p:
+        p.set_param("guess_min_points", 100000)
         p.build(out)
         assert p.stats()["bbox_guess"] == -1
-        _check_exact(p.query(tgt2, k), kd2.query(tgt2, k), "sampled box rejected")
+        _check_exact(p.query(tgt2, k), want, "sampled box rejected")
         p.rebuild()
         assert p.stats()["bbox_guess"] == 0                  # no second guess for this cloud
-        _check_exact(p.query(tgt2, k), kd2.query(tgt2, k), "exact box")
+        _check_exact(p.query(tgt2, k), want, "exact box")
