@@ -33,7 +33,7 @@ namespace {
 
 constexpr int WG = 256;
 constexpr int GL = 8;   // lanes per target
-constexpr int PT_RING_LIMIT = 8;   // rings walked shell by shell before the group kernel sweeps the blocks instead
+constexpr int PT_RING_LIMIT = 8;   // least number of rings walked shell by shell before the group kernel sweeps the blocks instead
 
 __device__ inline bool key_lt(double ad, uint32_t ai, double bd, uint32_t bi) { return ad < bd || (ad == bd && ai < bi); }
 
@@ -330,6 +330,7 @@ __global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __res
   }
 
   // ---- rings >= 2: only while something outside the scanned box can still beat the limit ---------------------------
+  const int ring_limit = max(PT_RING_LIMIT, (int)cbrtf(0.07f * (float)gp.nblocks));
   for (int r = 1;; ++r) {
     // every unscanned point lies beyond one of the box faces that still has cells behind it
     bool covered = true;
@@ -343,10 +344,11 @@ __global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __res
     if (covered) break;
     dout = fmax(dout - PT_CELL_EPS, 0.0);
     if (dout * dout * T.h2 > top.lim_d) break;
-    if (r >= PT_RING_LIMIT) {
+    if (r >= ring_limit) {
       // Far from the points (a stray target, a gap in the cloud): walking ever larger, mostly empty shells costs O(r^2)
       // per ring.  Sweep the BLOCKS instead -- skip the empty ones, prune the others by their box, scan what is left --
-      // starting the list again so that no point is offered twice.  O(blocks) per such target, exact like the walk.
+      // starting the list again so that no point is offered twice.  O(blocks) per such target, exact like the walk; taken
+      // once the walk has cost about as much as the sweep will (ring_limit^3 ~ blocks / 14).
       top.init(L, k, bound2 ? bound2[tr.id] : INFINITY);
       const uint32_t nb = (uint32_t)gp.nblocks;
       for (uint32_t b0 = 0; b0 < nb; b0 += GL) {
