@@ -111,30 +111,35 @@ __global__ __launch_bounds__(WG) void bbox_kernel(const T* __restrict__ x, const
     }
   }
 }
-// bounding box of every `stride`-th point (a guess of the cloud's extent from ~1e6 points)
+// bounding box of a SAMPLE of the cloud (a guess of its extent): one run of WG consecutive points out of every
+// `stride` runs -- consecutive so that the loads coalesce (one point every 4 KB cost a TLB miss each: 1 ms for 1e6 points)
 template <class T>
 __global__ __launch_bounds__(WG) void bbox_sample_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, uint32_t n,
                                                          uint32_t stride, uint64_t* out6) {
   double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  const uint64_t i = ((uint64_t)blockIdx.x * WG + threadIdx.x) * stride;
-  if (i < n) {
+  const uint64_t span = (uint64_t)stride * WG;
+  for (uint64_t i = (uint64_t)blockIdx.x * span + threadIdx.x; i < n; i += (uint64_t)gridDim.x * span) {
     const double v[3] = {(double)x[i], (double)y[i], (double)z[i]};
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { mn[a] = v[a]; mx[a] = v[a]; }
+    for (int a = 0; a < 3; ++a) { mn[a] = fmin(mn[a], v[a]); mx[a] = fmax(mx[a], v[a]); }
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mn[a] = fmin(mn[a], __shfl_xor(mn[a], o)); mx[a] = fmax(mx[a], __shfl_xor(mx[a], o)); }
   }
+  // few workgroups, one set of atomics each: thousands of waves on six addresses serialise (measured ~1 ms)
+  __shared__ double wbox[WG / 64][6];
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      if (mn[a] <= mx[a]) {
-        atomicMin((unsigned long long*)&out6[a], (unsigned long long)enc_f64(mn[a]));
-        atomicMax((unsigned long long*)&out6[3 + a], (unsigned long long)enc_f64(mx[a]));
-      }
-    }
+    for (int a = 0; a < 3; ++a) { wbox[threadIdx.x >> 6][a] = mn[a]; wbox[threadIdx.x >> 6][3 + a] = mx[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double v = wbox[0][threadIdx.x];
+    for (int w = 1; w < WG / 64; ++w) v = threadIdx.x < 3 ? fmin(v, wbox[w][threadIdx.x]) : fmax(v, wbox[w][threadIdx.x]);
+    if (threadIdx.x < 3) { if (v != INFINITY) atomicMin((unsigned long long*)&out6[threadIdx.x], (unsigned long long)enc_f64(v)); }
+    else if (v != -INFINITY) atomicMax((unsigned long long*)&out6[threadIdx.x], (unsigned long long)enc_f64(v));
   }
 }
 __global__ void bbox_init_kernel(uint64_t* out6) {
@@ -609,8 +614,9 @@ void pt_launch_bbox(const T* x, const T* y, const T* z, uint32_t n, uint64_t* ou
 template <class T>
 void pt_launch_bbox_sample(const T* x, const T* y, const T* z, uint32_t n, uint32_t stride, uint64_t* out6, hipStream_t s) {
   if (!n) return;
-  const uint32_t cnt = (n + stride - 1) / stride;
-  hipLaunchKernelGGL(bbox_sample_kernel<T>, dim3((cnt + WG - 1) / WG), dim3(WG), 0, s, x, y, z, n, stride, out6);
+  const uint64_t span = (uint64_t)stride * WG;                      // one run of WG points per `span` points
+  const uint32_t runs = (uint32_t)((n + span - 1) / span);
+  hipLaunchKernelGGL(bbox_sample_kernel<T>, dim3(std::min<uint32_t>(runs, 256u)), dim3(WG), 0, s, x, y, z, n, stride, out6);
 }
 template void pt_launch_bbox_sample<float>(const float*, const float*, const float*, uint32_t, uint32_t, uint64_t*, hipStream_t);
 template void pt_launch_bbox_sample<double>(const double*, const double*, const double*, uint32_t, uint32_t, uint64_t*, hipStream_t);

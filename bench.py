@@ -61,9 +61,9 @@ PMC_KERNEL = {"bbox_reduce": "bbox_kernel", "pass1_histogram": "hist_chunk_kerne
 
 def pmc_traffic(kernel, workload, world):
     """HBM bytes of one launch of `kernel` from the committed rocprofv3 PMC passes of the same workload
-    (profiles/r01_v8_c4_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE doubled as
+    (profiles/r01_v9_c4_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE doubled as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950).  None when no matching profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_v8_c4_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_v9_c4_pmc_traffic.json")
     if workload != "C4" or world != 1 or not os.path.exists(path):
         return None
     with open(path) as f:

@@ -566,7 +566,7 @@ def test_sampled_bounding_box_and_its_fallback(pkg, oracle):
         p.rebuild()
         assert p.stats()["bbox_guess"] == 1
     out = src.copy()
-    out[:, 12345] = (3.0, -2.0, 7.5)                        # not on the sample's stride
+    out[:, 12345] = (3.0, -2.0, 7.5)                        # not in one of the sampled runs
     tgt2 = np.concatenate([tgt, np.array([[2.9, 3.0], [-1.9, -2.0], [7.4, 7.5]], np.float32)], axis=1)
     want = oracle.KdTree(out).query(tgt2, k)
     with pkg.PointsTransfer(device=0, rho=0.5) as p:

@@ -25,10 +25,10 @@ def per_dispatch(path, counter):
             out[int(r["Dispatch_Id"])] = (short(r["Kernel_Name"]), float(r["Counter_Value"]))
     return out
 def last_step(path, counter):
-    """Sum over the dispatches of the LAST hot-path step of the run: from its bbox_kernel to the end."""
+    """Sum over the dispatches of the LAST hot-path step of the run: from its (sampled) bbox kernel to the end."""
     d = per_dispatch(path, counter)
     ids = sorted(d)
-    starts = [i for i, k in enumerate(ids) if d[k][0] == "bbox_kernel"]
+    starts = [i for i, k in enumerate(ids) if d[k][0] in ("bbox_kernel", "bbox_sample_kernel")]
     return sum(d[k][1] for k in ids[starts[-1]:]) if starts else None
 f = largest(sys.argv[1], "FETCH_SIZE"); w = largest(sys.argv[2], "WRITE_SIZE")
 out = {"workload": sys.argv[3] if len(sys.argv) > 3 else "", "kernels": {}}
