@@ -66,3 +66,30 @@ def test_random_configuration_matches_oracle(pkg, oracle, case):
     what = "case %d: %s n=%d m=%d k=%d rho=%g tile=%d f64=%d" % (case, kind, n, m, k, rho, tile, f64)
     assert np.array_equal(gi, wi), what + ": indices differ in %d rows" % int((gi != wi).any(axis=1).sum())
     assert np.array_equal(gd, wd), what + ": d2 differ"
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("PT_STRESS_BLEND_CASES", "10"))))
+def test_random_fused_blend_matches_oracle(pkg, oracle, case):
+    """The fused k-NN + blend call on generated clouds (uniform and clustered, both blend modes, every tile geometry):
+    neighbours bit-exact, blended colour / normal within the path's 1e-5."""
+    import torch
+    rng = np.random.default_rng(5000 + case)
+    n = int(rng.choice([2000, 40000, 300000])); m = int(rng.choice([1, 500, 12000]))
+    k = int(rng.choice([1, 4, 8, 13, 16, 20, 27, 32])); mode = int(rng.integers(0, 2)); tile = int(rng.choice([1, 2, 3, 0]))
+    dist = int(rng.integers(0, 2)); seed = int(rng.integers(1, 1 << 30))
+    rho = rng.choice([0.0, 2.0, 5.0, 15.0])
+    kw = dict(k_hint=k) if rho == 0.0 else dict(rho=float(rho))
+    with pkg.PointsTransfer(device=0, **kw) as p:
+        p.set_param("tile", tile)
+        p.build_synth(n, seed, dist=dist)
+        p.targets_synth(m, seed, dist=dist)
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        rgb = torch.empty((m, 3), dtype=torch.float32, device="cuda"); nrm = torch.empty((m, 3), dtype=torch.float32, device="cuda")
+        p.query_blend_resident_dev(k, mode, idx, d2, rgb, nrm)
+        torch.cuda.synchronize()
+    src = oracle.synth_xyz(seed, 0, n, dist=dist, n_total=n, m_total=m); tgt = oracle.synth_xyz(seed, 1, m, dist=dist, n_total=n, m_total=m)
+    wi, wd = oracle.KdTree(src).query(tgt, k)
+    what = "case %d: n=%d m=%d k=%d mode=%d tile=%d dist=%d rho=%g" % (case, n, m, k, mode, tile, dist, rho)
+    assert np.array_equal(idx.cpu().numpy().view(np.uint32), wi) and np.array_equal(d2.cpu().numpy(), wd), what
+    rc, rn = oracle.blend(wi, wd, oracle.synth_rgb(seed, n), oracle.synth_nrm(seed, n), mode)
+    assert np.abs(rgb.cpu().numpy() - rc).max() / 255 <= 1e-5 and np.abs(nrm.cpu().numpy() - rn).max() <= 1e-5, what
