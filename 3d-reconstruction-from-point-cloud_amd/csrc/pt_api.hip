@@ -64,7 +64,7 @@ struct pt_ctx {
   DevBuf ttb_mem;
 
   // scratch
-  DevBuf bbox6, counter, q_idx, q_d2, b_rgb, b_nrm, aos_stage, misc, bounds, todo;
+  DevBuf bbox6, counter, q_idx, q_d2, b_rgb, b_nrm, aos_stage, misc, bounds, todo, retry;
   uint64_t* h_bbox = nullptr;   // pinned
   uint32_t* h_counter = nullptr;
 
@@ -364,9 +364,25 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
       const int tile_small = c->tile == 2 || (c->tile == 1 && (double)c->n / cells * 1000.0 * 1.05 <= (double)(k <= 8 ? PT_TILE_CAP_SMALL_8 : PT_TILE_CAP_SMALL_16));
       uint32_t* todo_n = (uint32_t*)c->counter.p + 4;
       HIPCHK(c, hipMemsetAsync(todo_n, 0, 4, c->stream));
+      const Attr* battr = br ? (const Attr*)c->attr.p : nullptr;
+      const bool second_chance = tile_small && k <= 16;         // small geometry: over-budget blocks get the large one
+      uint32_t* retry_n = (uint32_t*)c->counter.p + 5;
+      if (second_chance) {
+        HIPCHK(c, hipMemsetAsync(retry_n, 0, 4, c->stream));
+        RES(c, c->retry, (size_t)c->gp.nblocks * sizeof(uint32_t));
+      }
       pt_launch_knn_tile(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, c->ttb.block_start, k, idx_dev, d2_dev,
-                         (uint32_t*)c->todo.p, todo_n, tile_small, br ? (const Attr*)c->attr.p : nullptr, (uint32_t)c->n_total, br ? br->mode : 0,
-                         br ? br->rgb_out : nullptr, br ? br->nrm_out : nullptr, c->stream);
+                         (uint32_t*)c->todo.p, todo_n, tile_small, battr, (uint32_t)c->n_total, br ? br->mode : 0,
+                         br ? br->rgb_out : nullptr, br ? br->nrm_out : nullptr, nullptr, 0, second_chance ? (uint32_t*)c->retry.p : nullptr,
+                         retry_n, c->stream);
+      if (second_chance) {
+        HIPCHK(c, hipMemcpyAsync(c->h_counter + 5, retry_n, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));            // (one short read-back; usually 0 blocks and no launch)
+        if (c->h_counter[5])
+          pt_launch_knn_tile(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, c->ttb.block_start, k, idx_dev, d2_dev,
+                             (uint32_t*)c->todo.p, todo_n, 0, battr, (uint32_t)c->n_total, br ? br->mode : 0, br ? br->rgb_out : nullptr,
+                             br ? br->nrm_out : nullptr, (const uint32_t*)c->retry.p, c->h_counter[5], nullptr, nullptr, c->stream);
+      }
       pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, nullptr, idx_dev, d2_dev,
                           (const uint32_t*)c->todo.p, todo_n, c->stream);
       if (br)   // the targets the tile kernel handed over get their blend from the lists the group kernel just wrote
@@ -475,7 +491,7 @@ void pt_ctx_destroy(pt_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in_xyz, &c->in_gidx, &c->attr, &c->rec, &c->rec_tmp, &c->cell_start, &c->stb_mem, &c->t_xyz, &c->t_gidx, &c->trec,
-                   &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr};
+                   &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr, &c->retry};
   for (DevBuf* b : all) release(c, *b);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);

@@ -58,8 +58,9 @@ void pt_launch_knn(const GridParams& gp, const Rec* src, const uint32_t* cell_st
 constexpr int PT_TILE_CAP_SMALL_8 = 4400, PT_TILE_CAP_SMALL_16 = 3888, PT_TILE_CAP_LARGE = 8448, PT_TILE_CAP_WIDE = 8960;
 constexpr int PT_TILE_MAX_K = 32;      // beyond this the group kernel answers everything
 void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* cell_start, const RecF* tgt, const uint32_t* tblock_start,
-                        int k, uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int small, const Attr* attr, uint32_t n_attr,
-                        int mode, float* rgb_out, float* nrm_out, hipStream_t s);
+                        int k, uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int geometry, const Attr* attr, uint32_t n_attr,
+                        int mode, float* rgb_out, float* nrm_out, const uint32_t* blocks, uint32_t nblocks_listed, uint32_t* retry,
+                        uint32_t* retry_n, hipStream_t s);
 void pt_launch_merge(const uint32_t* idx_lists, const double* d2_lists, int g, uint32_t m, int k, uint32_t* idx_out,
                      double* d2_out, hipStream_t s);
 template <class T>

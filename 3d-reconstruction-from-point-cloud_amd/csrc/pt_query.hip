@@ -492,12 +492,15 @@ __device__ inline void glds16(const uint4* g, uint4* lbase) {
 
 // attribute blend fused into the tile kernel (BLEND): the table, its length, the mode and the two outputs
 struct TileBlend { const Attr* attr; uint32_t n_attr; int mode; float* rgb_out; float* nrm_out; };
+// Second chance for blocks whose region is over this geometry's LDS budget but within the large geometry's: their ids go
+// to `retry` (retry != null), and a second launch (blocks != null: blockIdx.x indexes that list) takes them.
+struct TileBlocks { const uint32_t* blocks; uint32_t* retry; uint32_t* retry_n; uint32_t retry_cap; };
 
 template <int K, int TILE_CAP, int TWG, bool WIDE = false, bool BLEND = false>
 __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(GridParams gp, const RecF* __restrict__ src, const uint32_t* __restrict__ cs,
                                                         const RecF* __restrict__ tgt, const uint32_t* __restrict__ tblock_start, int k,
                                                         uint32_t* __restrict__ out_idx, double* __restrict__ out_d2,
-                                                        uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_n, TileBlend bl) {
+                                                        uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_n, TileBlend bl, TileBlocks tb) {
   constexpr int NW = TWG / 64;
   constexpr int TILE_QUADS = TWG / 4;
   constexpr int TILE_QCAP = TileQ<K, WIDE>::CAP, TILE_LCAP = TileQ<K, WIDE>::LCAP;
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
   static_assert(sizeof(queue) >= 5 * TILE_R * TILE_R * sizeof(uint32_t), "rowdesc aliases the queue");
   static_assert(TILE_CAP < 65536, "LDS offsets are 16-bit");
 
-  const uint32_t b = blockIdx.x;
+  const uint32_t b = tb.blocks ? tb.blocks[blockIdx.x] : blockIdx.x;
   const uint32_t ts = tblock_start[b], te = tblock_start[b + 1];   // (waited for only after the cell-table loads below are out)
   // block id -> cell origin of the block
   const uint32_t macro = b >> 9, m9 = b & 511u;
@@ -575,8 +578,12 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
   }
   __syncthreads();
   const uint32_t P = ptotal;
-  if (P > (uint32_t)TILE_CAP) {                     // denser than the LDS budget: the group kernel takes the whole tile
-    for (uint32_t t = ts + threadIdx.x; t < te; t += TWG) todo[atomicAdd(todo_n, 1u)] = t;
+  if (P > (uint32_t)TILE_CAP) {                     // denser than the LDS budget
+    if (tb.retry && P <= tb.retry_cap) {            // ... but not than the large geometry's: that launch takes the block
+      if (threadIdx.x == 0) tb.retry[atomicAdd(tb.retry_n, 1u)] = b;
+    } else {                                        // the group kernel takes the whole tile
+      for (uint32_t t = ts + threadIdx.x; t < te; t += TWG) todo[atomicAdd(todo_n, 1u)] = t;
+    }
     return;
   }
   // ---- B: stage the region, HBM -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, per-lane
@@ -957,22 +964,28 @@ template void pt_launch_knn<RecD>(const GridParams&, const RecD*, const uint32_t
                                   const uint32_t*, const uint32_t*, hipStream_t);
 
 // tile kernel over all blocks; targets it cannot settle are appended to todo[*todo_n] (todo_n zeroed by the caller).
-// `small` selects the two-workgroups-per-CU geometry (regions of <= PT_TILE_CAP_SMALL_* records).  With `attr` the
-// neighbours' attributes are blended in the same pass (rgb_out / nrm_out rows of the settled targets only).
+// geometry 1 = the two-workgroups-per-CU geometry (regions of <= PT_TILE_CAP_SMALL_* records), 0 = large.  With `attr` the
+// neighbours' attributes are blended in the same pass (rgb_out / nrm_out rows of the settled targets only).  `retry`:
+// blocks over the small budget but within the large one are listed there instead of going to `todo`; `blocks`: run over
+// such a list (nblocks_listed entries) instead of every block.
 void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* cell_start, const RecF* tgt, const uint32_t* tblock_start, int k,
-                        uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int small, const Attr* attr, uint32_t n_attr, int mode,
-                        float* rgb_out, float* nrm_out, hipStream_t s) {
-  const uint32_t nb = (uint32_t)gp.nblocks;
+                        uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int geometry, const Attr* attr, uint32_t n_attr, int mode,
+                        float* rgb_out, float* nrm_out, const uint32_t* blocks, uint32_t nblocks_listed, uint32_t* retry, uint32_t* retry_n,
+                        hipStream_t s) {
+  const uint32_t nb = blocks ? nblocks_listed : (uint32_t)gp.nblocks;
+  if (!nb) return;
   const TileBlend bl{attr, n_attr, mode, rgb_out, nrm_out};
+  const TileBlocks tbk{blocks, retry, retry_n, (uint32_t)PT_TILE_CAP_LARGE};
 #define PT_TILE_LAUNCH(KK, CAP, TH, WD)                                                                                                          \
   do {                                                                                                                                           \
     if (attr)                                                                                                                                    \
       hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH, WD, true>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, \
-                         out_d2, todo, todo_n, bl);                                                                                              \
+                         out_d2, todo, todo_n, bl, tbk);                                                                                         \
     else                                                                                                                                         \
       hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH, WD, false>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k,         \
-                         out_idx, out_d2, todo, todo_n, bl);                                                                                     \
+                         out_idx, out_d2, todo, todo_n, bl, tbk);                                                                                \
   } while (0)
+  const int small = geometry == 1;
   if (k > 24) PT_TILE_LAUNCH(32, PT_TILE_CAP_WIDE, 512, true);      // wide queue, 512 threads, one workgroup per CU
   else if (small && k <= 16) {       // (K = 32 needs more registers than two workgroups per CU leave: large geometry only)
     if (k <= 8) PT_TILE_LAUNCH(8, PT_TILE_CAP_SMALL_8, 512, false);
