@@ -516,7 +516,8 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
   static_assert(sizeof(queue) >= 5 * TILE_R * TILE_R * sizeof(uint32_t), "rowdesc aliases the queue");
   static_assert(TILE_CAP < 65536, "LDS offsets are 16-bit");
 
-  const uint32_t b = tb.blocks ? tb.blocks[blockIdx.x] : blockIdx.x;
+  uint32_t b = blockIdx.x;
+  if constexpr (!WIDE) { if (tb.blocks) b = tb.blocks[blockIdx.x]; }       // (the wide variant is never run over a list)
   const uint32_t ts = tblock_start[b], te = tblock_start[b + 1];   // (waited for only after the cell-table loads below are out)
   // block id -> cell origin of the block
   const uint32_t macro = b >> 9, m9 = b & 511u;
@@ -579,8 +580,10 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
   __syncthreads();
   const uint32_t P = ptotal;
   if (P > (uint32_t)TILE_CAP) {                     // denser than the LDS budget
-    if (tb.retry && P <= tb.retry_cap) {            // ... but not than the large geometry's: that launch takes the block
-      if (threadIdx.x == 0) tb.retry[atomicAdd(tb.retry_n, 1u)] = b;
+    bool again = false;
+    if constexpr (!WIDE) again = tb.retry && P <= tb.retry_cap;
+    if (again) {                                    // ... but not than the large geometry's: that launch takes the block
+      if constexpr (!WIDE) { if (threadIdx.x == 0) tb.retry[atomicAdd(tb.retry_n, 1u)] = b; }
     } else {                                        // the group kernel takes the whole tile
       for (uint32_t t = ts + threadIdx.x; t < te; t += TWG) todo[atomicAdd(todo_n, 1u)] = t;
     }
