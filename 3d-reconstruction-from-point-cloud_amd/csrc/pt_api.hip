@@ -223,7 +223,7 @@ int rebuild(pt_ctx* c) {
     { int r = source_bbox(c, guessed ? 1024u : 1u, mn, mx); if (r != PT_OK) return r; }
   }
   // Grid choice.  The first guess assumes the cloud fills its bounding box; finalize counts the non-empty cells, and when
-  // those hold far more than rho points each (surfaces, clusters) the cell size is refined -- at most twice, and never
+  // those hold far more than rho points each (surfaces, clusters) the cell size is refined -- at most three times, and never
   // beyond what the dense cell table allows (choose_grid coarsens again if the macro-block limit is hit).
   double force_h = 0.0;
   uint32_t nblocks = 0;
@@ -286,10 +286,10 @@ int rebuild(pt_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const double occupied = std::max<double>(1.0, c->h_counter[8]);
     c->st.rho_occupied = (double)c->n / occupied;
-    if (iter >= 2 || c->st.rho_occupied <= 2.5 * c->rho) break;
+    if (iter >= 3 || c->st.rho_occupied <= 1.5 * c->rho) break;
     const double h_old = c->gp.h;
     const int d0 = c->gp.dim[0], d1 = c->gp.dim[1], d2 = c->gp.dim[2];
-    force_h = h_old * std::pow(c->rho * 1.25 / c->st.rho_occupied, 1.0 / 2.5);     // occupied cells grow ~ h^-2 .. h^-3
+    force_h = h_old * std::pow(c->rho * 1.25 / c->st.rho_occupied, 1.0 / 2.2);     // occupied cells grow ~ h^-2 .. h^-3
     GridParams probe = c->gp;
     choose_grid(c, mn, mx, force_h);
     const bool changed = c->gp.dim[0] != d0 || c->gp.dim[1] != d1 || c->gp.dim[2] != d2;
@@ -336,6 +336,8 @@ int copy_in(pt_ctx* c, void* dst, const void* src, size_t bytes, int on_device) 
   return PT_OK;
 }
 
+inline bool contrast_last(const pt_ctx* c) { return c->tile == 1 && c->adaptive && c->st.rho_occupied > 1.5 * c->rho; }
+
 // optional second half of a query: blend the neighbours' attributes (fused into the tile kernel where that runs)
 struct BlendReq { int mode; float* rgb_out; float* nrm_out; };
 
@@ -358,7 +360,11 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     // targets only need to be grouped by block (tile kernel) -- the cell-level pass is skipped
     const RecF* tsorted = pt_launch_grid_sort<float, RecF>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecF*)c->trec.p, (RecF*)c->trec_tmp.p, nullptr, c->ttb, false, c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    if (c->tile && !bound2_dev && m && k <= PT_TILE_MAX_K) {
+    // A cloud whose occupied cells stay far above rho even after refinement (blobs, strong density contrast) overflows
+    // most tile regions: measured on the clustered generator the group kernel alone is ~8 % faster than tile kernel +
+    // hand-over, so the automatic mode goes straight to it.
+    const bool contrast = c->tile == 1 && c->adaptive && c->st.rho_occupied > 1.5 * c->rho;
+    if (c->tile && !contrast && !bound2_dev && m && k <= PT_TILE_MAX_K) {
       // regions (10^3 cells) that fit the small capacity with headroom run the two-workgroups-per-CU geometry
       const double cells = (double)c->gp.dim[0] * c->gp.dim[1] * c->gp.dim[2];
       const int tile_small = c->tile == 2 || (c->tile == 1 && (double)c->n / cells * 1000.0 * 1.05 <= (double)(k <= 8 ? PT_TILE_CAP_SMALL_8 : PT_TILE_CAP_SMALL_16));
@@ -417,7 +423,7 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     c->st.ms_query = b;
     c->st.ms_kernel[6] = a;
     c->st.ms_kernel[7] = b;
-    c->st.n_leftover = (c->tile && !bound2_dev && m && k <= PT_TILE_MAX_K && ttype == PT_F32) ? c->h_counter[4] : 0;
+    c->st.n_leftover = (c->tile && !contrast_last(c) && !bound2_dev && m && k <= PT_TILE_MAX_K && ttype == PT_F32) ? c->h_counter[4] : 0;
   }
   return PT_OK;
 }
