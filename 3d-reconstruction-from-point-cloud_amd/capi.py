@@ -21,7 +21,7 @@ SYMBOLS = [
     "pt_ctx_create", "pt_ctx_destroy", "pt_set_stream", "pt_set_param", "pt_last_error", "pt_stats", "pt_synchronize",
     "pt_build_aos", "pt_build_soa", "pt_build_soa_indexed", "pt_set_attributes", "pt_build_synth", "pt_rebuild",
     "pt_num_source", "pt_query_aos", "pt_query_soa", "pt_targets_synth", "pt_num_targets", "pt_query_resident", "pt_query_blend_resident",
-    "pt_resident_target_ids", "pt_resident_target_xyz", "pt_blend", "pt_blend_dev", "pt_pca_normals",
+    "pt_resident_target_ids", "pt_resident_target_xyz", "pt_blend", "pt_blend_dev", "pt_blend_weighted", "pt_blend_weighted_dev", "pt_pca_normals",
     "pt_pca_normals_dev", "pt_merge_candidates_dev", "pt_slab_need_dev", "pt_query_bounded_dev",
 ]
 
@@ -85,6 +85,8 @@ def lib():
         "pt_resident_target_xyz": (i32, [p, p]),
         "pt_blend": (i32, [p, p, p, u64, i32, i32, p, p]),
         "pt_blend_dev": (i32, [p, p, p, u64, i32, i32, p, p]),
+        "pt_blend_weighted": (i32, [p, p, p, u64, i32, p, p]),
+        "pt_blend_weighted_dev": (i32, [p, p, p, u64, i32, p, p]),
         "pt_pca_normals": (i32, [p, p, u64, i32, p]),
         "pt_pca_normals_dev": (i32, [p, p, u64, i32, p]),
         "pt_merge_candidates_dev": (i32, [p, p, p, i32, u64, i32, p, p]),

@@ -799,6 +799,40 @@ int pt_blend(pt_ctx* c, const uint32_t* idx, const double* d2_or_null, uint64_t 
   return PT_OK;
 }
 
+int pt_blend_weighted_dev(pt_ctx* c, const uint32_t* idx_dev, const double* w_dev, uint64_t m, int k, float* rgb_out_dev, float* nrm_out_dev) {
+  if (!c) return PT_ERR_ARG;
+  if (!c->has_attr) return fail(c, PT_ERR_STATE, "no attribute table resident");
+  if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k out of range");
+  if (m && (!idx_dev || !w_dev)) return fail(c, PT_ERR_ARG, "null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  pt_launch_blend_weighted(idx_dev, w_dev, (uint32_t)m, k, (const Attr*)c->attr.p, (uint32_t)c->n_total, rgb_out_dev, nrm_out_dev, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return finish(c);
+}
+
+int pt_blend_weighted(pt_ctx* c, const uint32_t* idx, const double* w, uint64_t m, int k, float* rgb_out, float* nrm_out) {
+  if (!c) return PT_ERR_ARG;
+  if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k out of range");
+  if (m && (!idx || !w)) return fail(c, PT_ERR_ARG, "null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  RES(c, c->q_idx, std::max<uint64_t>(m, 1) * k * sizeof(uint32_t));
+  RES(c, c->q_d2, std::max<uint64_t>(m, 1) * k * sizeof(double));
+  RES(c, c->b_rgb, std::max<uint64_t>(m, 1) * 12);
+  RES(c, c->b_nrm, std::max<uint64_t>(m, 1) * 12);
+  { int r = copy_in(c, c->q_idx.p, idx, m * k * sizeof(uint32_t), 0); if (r) return r; }
+  { int r = copy_in(c, c->q_d2.p, w, m * k * sizeof(double), 0); if (r) return r; }
+  const int sync_save = c->sync;
+  c->sync = 1;
+  int r = pt_blend_weighted_dev(c, (const uint32_t*)c->q_idx.p, (const double*)c->q_d2.p, m, k, (float*)c->b_rgb.p, (float*)c->b_nrm.p);
+  c->sync = sync_save;
+  if (r != PT_OK) return r;
+  if (m) {
+    if (rgb_out) HIPCHK(c, hipMemcpy(rgb_out, c->b_rgb.p, m * 12, hipMemcpyDeviceToHost));
+    if (nrm_out) HIPCHK(c, hipMemcpy(nrm_out, c->b_nrm.p, m * 12, hipMemcpyDeviceToHost));
+  }
+  return PT_OK;
+}
+
 int pt_pca_normals_dev(pt_ctx* c, const uint32_t* idx_dev, uint64_t m, int k, float* nrm_out_dev) {
   if (!c) return PT_ERR_ARG;
   if (c->src_type < 0) return fail(c, PT_ERR_STATE, "no source cloud resident");

@@ -172,6 +172,30 @@ __global__ __launch_bounds__(WG) void blend_kernel(const uint32_t* __restrict__ 
   blend_one(idx, d2, t, k, mode, attr, n_attr, rgb_out, nrm_out);
 }
 
+// the reference's own mix (src/pointsTransfer.cpp:95-97: double weight x int colour, summed left to right in double, stored
+// to a float) for k terms with caller-given weights; no normalisation
+__global__ __launch_bounds__(WG) void blend_weighted_kernel(const uint32_t* __restrict__ idx, const double* __restrict__ w, uint32_t m, int k,
+                                                            const Attr* __restrict__ attr, uint32_t n_attr, float* __restrict__ rgb_out,
+                                                            float* __restrict__ nrm_out) {
+  const uint32_t t = blockIdx.x * WG + threadIdx.x;
+  if (t >= m) return;
+  double c[3] = {0, 0, 0}, nn[3] = {0, 0, 0};
+  bool first = true;
+  for (int j = 0; j < k; ++j) {
+    const uint32_t id = idx[(size_t)t * k + j];
+    if (id == PT_NOIDX_U || id >= n_attr) continue;
+    const double wj = w[(size_t)t * k + j];
+    const Attr a = pt_gather_attr(attr, id);
+    const double pc[3] = {wj * (double)(a.rgba & 0xFFu), wj * (double)((a.rgba >> 8) & 0xFFu), wj * (double)((a.rgba >> 16) & 0xFFu)};
+    const double pn[3] = {wj * (double)a.nx, wj * (double)a.ny, wj * (double)a.nz};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { c[q] = first ? pc[q] : c[q] + pc[q]; nn[q] = first ? pn[q] : nn[q] + pn[q]; }
+    first = false;
+  }
+  if (rgb_out) { rgb_out[3 * (size_t)t] = (float)c[0]; rgb_out[3 * (size_t)t + 1] = (float)c[1]; rgb_out[3 * (size_t)t + 2] = (float)c[2]; }
+  if (nrm_out) { nrm_out[3 * (size_t)t] = (float)nn[0]; nrm_out[3 * (size_t)t + 1] = (float)nn[1]; nrm_out[3 * (size_t)t + 2] = (float)nn[2]; }
+}
+
 // the same for the targets on a list of positions in the sorted target array (what the tile kernel left to the group kernel)
 __global__ __launch_bounds__(WG) void blend_list_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_n,
                                                         const RecF* __restrict__ tgt, const uint32_t* __restrict__ idx, const double* __restrict__ d2,
@@ -338,6 +362,11 @@ void pt_launch_blend(const uint32_t* idx, const double* d2, uint32_t m, int k, i
                      float* nrm_out, hipStream_t s) {
   if (!m) return;
   hipLaunchKernelGGL(blend_kernel, grid_for(m), dim3(WG), 0, s, idx, d2, m, k, mode, attr, n_attr, rgb_out, nrm_out);
+}
+void pt_launch_blend_weighted(const uint32_t* idx, const double* w, uint32_t m, int k, const Attr* attr, uint32_t n_attr, float* rgb_out,
+                              float* nrm_out, hipStream_t s) {
+  if (!m) return;
+  hipLaunchKernelGGL(blend_weighted_kernel, grid_for(m), dim3(WG), 0, s, idx, w, m, k, attr, n_attr, rgb_out, nrm_out);
 }
 void pt_launch_blend_list(const uint32_t* list, const uint32_t* list_n, uint32_t m_max, const RecF* tgt, const uint32_t* idx, const double* d2, int k,
                           int mode, const Attr* attr, uint32_t n_attr, float* rgb_out, float* nrm_out, hipStream_t s) {

@@ -80,6 +80,8 @@ void pt_launch_synth_attr(uint64_t seed, uint32_t n_total, Attr* attr, hipStream
 // reference AoS records (80-B stride, device copy) -> planar f64 xyz + attribute table
 void pt_launch_aos_split(const void* aos, uint32_t n, double* x, double* y, double* z, Attr* attr, hipStream_t s);
 void pt_launch_pack_attr(const uint8_t* rgb, const float* nrm, uint32_t n, Attr* attr, hipStream_t s);
+void pt_launch_blend_weighted(const uint32_t* idx, const double* w, uint32_t m, int k, const Attr* attr, uint32_t n_attr, float* rgb_out,
+                              float* nrm_out, hipStream_t s);
 void pt_launch_blend_list(const uint32_t* list, const uint32_t* list_n, uint32_t m_max, const RecF* tgt, const uint32_t* idx, const double* d2, int k,
                           int mode, const Attr* attr, uint32_t n_attr, float* rgb_out, float* nrm_out, hipStream_t s);
 void pt_launch_blend(const uint32_t* idx, const double* d2, uint32_t m, int k, int mode, const Attr* attr, uint32_t n_attr,

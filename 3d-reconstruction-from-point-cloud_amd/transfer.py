@@ -201,6 +201,15 @@ class PointsTransfer:
         self._chk(self._L.pt_blend(self._h, _ptr(idx), _ptr(d2c), m, k, mode, _ptr(rgb), _ptr(nrm)))
         return rgb, nrm
 
+    def blend_weighted(self, idx, w):
+        """out = sum_j w[t, j] * a[idx[t, j]] -- the reference's mix formula (src/pointsTransfer.cpp:95-97) with caller weights."""
+        idx = np.ascontiguousarray(idx, np.uint32); w = np.ascontiguousarray(w, np.float64)
+        m, k = idx.shape
+        assert w.shape == (m, k)
+        rgb = np.empty((m, 3), np.float32); nrm = np.empty((m, 3), np.float32)
+        self._chk(self._L.pt_blend_weighted(self._h, _ptr(idx), _ptr(w), m, k, _ptr(rgb), _ptr(nrm)))
+        return rgb, nrm
+
     def blend_dev(self, idx_dev, d2_dev, m, k, mode, rgb_out_dev, nrm_out_dev):
         self._adopt_torch_stream()
         self._chk(self._L.pt_blend_dev(self._h, _ptr(idx_dev), _ptr(d2_dev), m, k, mode, _ptr(rgb_out_dev), _ptr(nrm_out_dev)))

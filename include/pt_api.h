@@ -164,6 +164,13 @@ int  pt_blend(pt_ctx*, const uint32_t* idx, const double* d2_or_null, uint64_t m
 /* device buffers in / out */
 int  pt_blend_dev(pt_ctx*, const uint32_t* idx_dev, const double* d2_dev_or_null, uint64_t m, int k,
                   int mode, float* rgb_out_dev, float* nrm_out_dev);
+/* The reference's own mix formula (src/pointsTransfer.cpp:95-97: `float c = bc0*c0 + bc1*c1 + bc2*c2`, double weights
+ * times int colours summed left to right in double, stored to a float; :100-102 assign it to an unsigned char) for k
+ * terms with CALLER-given weights w[m*k] -- with k = 3 and barycentric weights it is bit-for-bit that expression.  No
+ * normalisation; entries with idx = PT_NOIDX contribute nothing; normals get the same arithmetic. */
+int  pt_blend_weighted(pt_ctx*, const uint32_t* idx, const double* w, uint64_t m, int k, float* rgb_out, float* nrm_out);
+int  pt_blend_weighted_dev(pt_ctx*, const uint32_t* idx_dev, const double* w_dev, uint64_t m, int k,
+                           float* rgb_out_dev, float* nrm_out_dev);
 /* PCA normal of the k neighbours (BASELINE config 3); needs the whole cloud resident (no slabs). */
 int  pt_pca_normals(pt_ctx*, const uint32_t* idx, uint64_t m, int k, float* nrm_out);
 int  pt_pca_normals_dev(pt_ctx*, const uint32_t* idx_dev, uint64_t m, int k, float* nrm_out_dev);

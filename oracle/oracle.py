@@ -62,6 +62,7 @@ def lib():
         L.pto_num_threads.restype = i32
         L.pto_merge_candidates.argtypes = [p, p, i32, u64, i32, p, p]
         L.pto_blend.argtypes = [p, p, u64, i32, i32, p, p, p, p]
+        L.pto_blend_weighted.argtypes = [p, p, u64, i32, p, p, p, p]
         L.pto_pca_normals.argtypes = [p, u64, i32, p, u64, p, p, p]
         _lib = L
     return _lib
@@ -195,6 +196,18 @@ def blend(idx, d2, rgb, nrm, mode=0):
     nrm = None if nrm is None else np.ascontiguousarray(nrm, np.float32)
     ro = np.zeros((m, 3), np.float32); no = np.zeros((m, 3), np.float32)
     rc = lib().pto_blend(_ptr(idx), _ptr(d2), m, k, mode, _ptr(rgb), _ptr(nrm), _ptr(ro), _ptr(no))
+    assert rc == 0
+    return ro, no
+
+
+def blend_weighted(idx, w, rgb, nrm):
+    """The reference's mix formula (pointsTransfer.cpp:95-97) for k terms with caller-given weights."""
+    idx = np.ascontiguousarray(idx, np.uint32); w = np.ascontiguousarray(w, np.float64)
+    m, k = idx.shape
+    rgb = None if rgb is None else np.ascontiguousarray(rgb, np.uint8)
+    nrm = None if nrm is None else np.ascontiguousarray(nrm, np.float32)
+    ro = np.zeros((m, 3), np.float32); no = np.zeros((m, 3), np.float32)
+    rc = lib().pto_blend_weighted(_ptr(idx), _ptr(w), m, k, _ptr(rgb), _ptr(nrm), _ptr(ro), _ptr(no))
     assert rc == 0
     return ro, no
 

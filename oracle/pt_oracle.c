@@ -491,6 +491,37 @@ int pto_blend(const uint32_t* idx, const double* d2, uint64_t m, int k, int mode
 }
 
 /* ------------------------------------------------------------------------- */
+/* The reference's own blend, restated: pointsTransfer.cpp:95-97               */
+/*   float r = bc0 * c0.r() + bc1 * c1.r() + bc2 * c2.r();                     */
+/* (double weights times int colours, summed left to right in double, stored  */
+/* to a float; :100-102 then assign that float to an unsigned char).  Here for  */
+/* k terms with caller-given weights w[m][k]; no normalisation; entries with   */
+/* idx == PTO_NOIDX are skipped.  Normals get the same arithmetic (an           */
+/* extension: the reference mixes colours only).                                */
+/* ------------------------------------------------------------------------- */
+int pto_blend_weighted(const uint32_t* idx, const double* w, uint64_t m, int k, const uint8_t* rgb, const float* nrm,
+                       float* rgb_out, float* nrm_out) {
+  for (uint64_t t = 0; t < m; ++t) {
+    double c[3] = {0, 0, 0}, nn[3] = {0, 0, 0};
+    int first = 1;
+    for (int j = 0; j < k; ++j) {
+      const uint32_t id = idx[t * k + j];
+      if (id == PTO_NOIDX) continue;
+      const double wj = w[t * k + j];
+      for (int a = 0; a < 3; ++a) {
+        const double pc = rgb ? wj * (double)rgb[3 * (size_t)id + a] : 0.0, pn = nrm ? wj * (double)nrm[3 * (size_t)id + a] : 0.0;
+        c[a] = first ? pc : c[a] + pc;            /* p0 + p1 + p2: the first term is not added to a zero */
+        nn[a] = first ? pn : nn[a] + pn;
+      }
+      first = 0;
+    }
+    if (rgb_out) for (int a = 0; a < 3; ++a) rgb_out[3 * t + a] = (float)c[a];
+    if (nrm_out) for (int a = 0; a < 3; ++a) nrm_out[3 * t + a] = (float)nn[a];
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* PCA normal from the k neighbours (BUILD-DEFINED, BASELINE config 3; no      */
 /* reference counterpart): eigenvector of the smallest eigenvalue of the       */
 /* neighbours' 3x3 covariance (double, Jacobi), sign-oriented so that          */

@@ -577,3 +577,23 @@ def test_sampled_bounding_box_and_its_fallback(pkg, oracle):
         p.rebuild()
         assert p.stats()["bbox_guess"] == 0                  # no second guess for this cloud
         _check_exact(p.query(tgt2, k), want, "exact box")
+
+
+def test_weighted_blend_is_the_reference_mix_bit_for_bit(pkg, oracle):
+    """pt_blend_weighted against the oracle's restatement of pointsTransfer.cpp:95-97: identical floats (k = 3 barycentric
+    weights as in the reference, and longer lists with missing entries)."""
+    rng = np.random.default_rng(9)
+    n = 5000
+    src = rng.random((3, n), dtype=np.float32)
+    rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8); nrm = rng.standard_normal((n, 3)).astype(np.float32)
+    with pkg.PointsTransfer(device=0) as p:
+        p.build(src, rgb=rgb, nrm=nrm)
+        for m, k in ((4000, 3), (1000, 20), (1, 1)):
+            idx = rng.integers(0, n, size=(m, k)).astype(np.uint32)
+            idx[rng.random((m, k)) < 0.05] = 0xFFFFFFFF
+            w = rng.random((m, k))
+            if k == 3:
+                w /= w.sum(axis=1, keepdims=True)                                 # barycentric
+            gr, gn = p.blend_weighted(idx, w)
+            wr, wn = oracle.blend_weighted(idx, w, rgb, nrm)
+            assert np.array_equal(gr, wr) and np.array_equal(gn, wn), (m, k)

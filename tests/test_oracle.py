@@ -169,3 +169,23 @@ def test_kdtree_exact_ties_at_the_pruning_bound(oracle):
         bi, bd = oracle.knn_bruteforce(src, tgt, k)
         ki, kd = oracle.KdTree(src).query(tgt, k)
         assert np.array_equal(ki, bi) and np.array_equal(kd, bd), "lattice %d" % g
+
+
+def test_reference_mix_formula_known_answer(oracle):
+    """pointsTransfer.cpp:95-97 restated (oracle.blend_weighted): double weight x int colour, left-to-right double sum,
+    one rounding to float -- checked against the same expression written out in numpy float64."""
+    rgb = np.array([[255, 0, 10], [0, 255, 20], [7, 9, 250]], np.uint8)
+    nrm = np.array([[0, 0, 1], [0, 1, 0], [1, 0, 0]], np.float32)
+    bc = np.array([[0.2, 0.3, 0.5], [1.0 / 3, 1.0 / 3, 1.0 / 3], [1.0, 0.0, 0.0]])
+    idx = np.tile(np.arange(3, dtype=np.uint32), (3, 1))
+    got, gn = oracle.blend_weighted(idx, bc, rgb, nrm)
+    for t in range(3):
+        for c in range(3):
+            want = np.float32((bc[t, 0] * float(rgb[0, c]) + bc[t, 1] * float(rgb[1, c])) + bc[t, 2] * float(rgb[2, c]))
+            assert got[t, c] == want
+    assert np.array_equal(got[2], rgb[0].astype(np.float32)) and got[0, 0] == np.float32(0.2 * 255 + 0.0 + 0.5 * 7)
+    assert int(got[0, 2]) == 133                              # 0.2*10 + 0.3*20 + 0.5*250; :100-102 truncate the float into an unsigned char
+    # a missing neighbour contributes nothing
+    idx2 = idx.copy(); idx2[0, 1] = 0xFFFFFFFF
+    g2, _ = oracle.blend_weighted(idx2, bc, rgb, nrm)
+    assert g2[0, 1] == np.float32(0.2 * 0 + 0.5 * 9)
