@@ -673,6 +673,29 @@ int pt_targets_synth(pt_ctx* c, uint64_t m_total, uint64_t seed, int dist, int x
   return finish(c);
 }
 
+int pt_targets_soa(pt_ctx* c, const void* xyz, int xyz_type, uint64_t m, int on_device) {
+  if (!c) return PT_ERR_ARG;
+  { int r = check_n(c, m, "m"); if (r) return r; }
+  HIPCHK(c, hipSetDevice(c->device));
+  { int r = upload_xyz(c, c->t_xyz, xyz, xyz_type, m, on_device); if (r) return r; }      // (fp16 is widened to fp32 here)
+  c->tgt_type = xyz_type; c->m = m; c->t_has_gidx = false;
+  return finish(c);
+}
+
+int pt_targets_aos(pt_ctx* c, const pt_point* targets, uint64_t m) {
+  if (!c) return PT_ERR_ARG;
+  if (m && !targets) return fail(c, PT_ERR_ARG, "targets is null");
+  { int r = check_n(c, m, "m"); if (r) return r; }
+  HIPCHK(c, hipSetDevice(c->device));
+  RES(c, c->aos_stage, std::max<uint64_t>(m, 1) * sizeof(pt_point));
+  RES(c, c->t_xyz, std::max<uint64_t>(m, 1) * 3 * sizeof(double));
+  { int r = copy_in(c, c->aos_stage.p, targets, m * sizeof(pt_point), 0); if (r) return r; }
+  double* x = (double*)c->t_xyz.p;
+  pt_launch_aos_split(c->aos_stage.p, (uint32_t)m, x, x + m, x + 2 * m, nullptr, c->stream);
+  c->tgt_type = PT_F64; c->m = m; c->t_has_gidx = false;
+  return finish(c);
+}
+
 int pt_query_resident(pt_ctx* c, int k, uint32_t* idx_dev, double* d2_dev_or_null) {
   if (!c) return PT_ERR_ARG;
   if (c->tgt_type < 0) return fail(c, PT_ERR_STATE, "no resident targets");

@@ -166,6 +166,21 @@ class PointsTransfer:
     def targets_synth(self, m_total, seed, xyz_type=capi.F32, dist=capi.DIST_UNIFORM, slab_axis=-1, slab_lo=-math.inf, slab_hi=math.inf):
         self._chk(self._L.pt_targets_synth(self._h, m_total, seed, dist, xyz_type, slab_axis, slab_lo, slab_hi))
 
+    def set_targets(self, xyz, xyz_type=None):
+        """Make the caller's targets resident: planar (3, m) numpy array (host) or torch tensor (device, pass xyz_type)."""
+        if hasattr(xyz, "data_ptr"):
+            assert xyz_type is not None and xyz.dim() == 2 and xyz.shape[0] == 3 and xyz.is_contiguous()
+            self._adopt_torch_stream()
+            self._chk(self._L.pt_targets_soa(self._h, _ptr(xyz), xyz_type, xyz.shape[1], 1))
+            return
+        a, t = _planar(xyz, xyz_type)
+        self._chk(self._L.pt_targets_soa(self._h, _ptr(a), t, a.shape[1], 0))
+
+    def set_targets_aos(self, points):
+        a = np.ascontiguousarray(points)
+        assert a.dtype.itemsize == 80
+        self._chk(self._L.pt_targets_aos(self._h, _ptr(a), a.shape[0]))
+
     def query_resident_dev(self, k, idx_dev, d2_dev=None):
         self._adopt_torch_stream()
         self._chk(self._L.pt_query_resident(self._h, k, _ptr(idx_dev), _ptr(d2_dev)))

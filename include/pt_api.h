@@ -141,6 +141,11 @@ int  pt_query_soa(pt_ctx*, const void* xyz, int xyz_type, uint64_t m, int k, int
  * the same seed. */
 int  pt_targets_synth(pt_ctx*, uint64_t m_total, uint64_t seed, int dist, int xyz_type,
                       int slab_axis, double slab_lo, double slab_hi);
+/* Make the caller's own targets resident (planar xyz, host or device; or host AoS Point records = mesh vertices), so that
+ * pt_query_resident / pt_query_blend_resident work on them.  Same type rule as the queries: the targets' type must be the
+ * cloud's (fp16 is widened to fp32; AoS records are fp64 like a cloud built with pt_build_aos). */
+int  pt_targets_soa(pt_ctx*, const void* xyz, int xyz_type, uint64_t m, int on_device);
+int  pt_targets_aos(pt_ctx*, const pt_point* targets, uint64_t m);
 uint64_t pt_num_targets(pt_ctx*);
 /* Query the resident targets; idx/d2 are DEVICE buffers of m*k entries (d2 may be NULL). */
 int  pt_query_resident(pt_ctx*, int k, uint32_t* idx_dev, double* d2_dev_or_null);

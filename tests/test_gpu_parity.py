@@ -597,3 +597,34 @@ def test_weighted_blend_is_the_reference_mix_bit_for_bit(pkg, oracle):
             gr, gn = p.blend_weighted(idx, w)
             wr, wn = oracle.blend_weighted(idx, w, rgb, nrm)
             assert np.array_equal(gr, wr) and np.array_equal(gn, wn), (m, k)
+
+
+def test_caller_targets_made_resident(pkg, oracle):
+    """pt_targets_soa / pt_targets_aos: the caller's own targets behind pt_query_resident and the fused call -- same answers
+    as the transient query, host and device arrays, planar fp32 and AoS Point records."""
+    import torch
+    n, m, k, seed = 80000, 5000, 8, 0x7A
+    src = oracle.synth_xyz(seed, 0, n); tgt = oracle.synth_xyz(seed, 1, m)
+    rgbs = oracle.synth_rgb(seed, n); nrms = oracle.synth_nrm(seed, n)
+    want = oracle.KdTree(src).query(tgt, k)
+    wr, wn = oracle.blend(want[0], want[1], rgbs, nrms, 0)
+    with pkg.PointsTransfer(device=0) as p:
+        p.build(src, rgb=rgbs, nrm=nrms)
+        for dev_side in (False, True):
+            p.set_targets(torch.from_numpy(tgt).cuda() if dev_side else tgt, pkg.F32)
+            assert p.num_targets == m
+            idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+            rgb = torch.empty((m, 3), dtype=torch.float32, device="cuda"); nrm = torch.empty((m, 3), dtype=torch.float32, device="cuda")
+            p.query_blend_resident_dev(k, pkg.BLEND_MEAN, idx, d2, rgb, nrm)
+            torch.cuda.synchronize()
+            _check_exact((idx.cpu().numpy().view(np.uint32), d2.cpu().numpy()), want, "resident caller targets")
+            assert np.abs(rgb.cpu().numpy() - wr).max() / 255 <= TOL and np.abs(nrm.cpu().numpy() - wn).max() <= TOL
+    pts = np.zeros(n, dtype=pkg.POINT_DTYPE); pts["ver"] = src.T.astype(np.float64); pts["color"] = rgbs; pts["normal"] = nrms
+    tp = np.zeros(m, dtype=pkg.POINT_DTYPE); tp["ver"] = tgt.T.astype(np.float64)
+    with pkg.PointsTransfer(device=0) as p:
+        p.build_aos(pts)
+        p.set_targets_aos(tp)
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        p.query_resident_dev(k, idx, d2)
+        torch.cuda.synchronize()
+        _check_exact((idx.cpu().numpy().view(np.uint32), d2.cpu().numpy()), want, "resident AoS targets")
