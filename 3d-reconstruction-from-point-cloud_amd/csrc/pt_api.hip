@@ -46,6 +46,9 @@ struct pt_ctx {
   int src_type = -1;           // PT_F32 / PT_F64
   uint64_t n = 0, n_total = 0; // resident points; size of the attribute table
   DevBuf in_xyz, in_gidx, attr, rec, rec_tmp, cell_start;
+  DevBuf rec32;                // fp64 clouds: fp32 shadow of the sorted records (id = sorted position), the tile kernel's LDS image
+  bool rec32_valid = false;
+  float e_src = 0.f;           // fp64 clouds: largest rounding error of a source coordinate stored as fp32
   DevBuf posattr;              // fp32 clouds: {position, attributes} by original index for the PCA pass, built on first use
   bool has_gidx = false, has_attr = false, built = false, posattr_valid = false;
   uint64_t guess_min_points = 8u << 20;   // clouds at least this large lay their grid out from a sampled bounding box
@@ -143,6 +146,7 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
   tb.chunk_gsum = p; p += (nchunks / 64 + 2) * nbins1;
   tb.bid = bid_words ? (uint16_t*)p : nullptr;
   tb.occupied = nullptr;
+  tb.shadow32 = nullptr;
   tb.ev = nullptr;
   return PT_OK;
 }
@@ -253,6 +257,11 @@ int rebuild(pt_ctx* c) {
     RES(c, c->rec_tmp, std::max<size_t>(c->n, 1) * recsize(c->src_type));
     { int r = make_tables(c, c->stb_mem, c->stb, nblocks, (uint32_t)c->n, recsize(c->src_type)); if (r != PT_OK) return r; }
     c->stb.ev = c->sev;
+    c->rec32_valid = false;
+    if (c->src_type == PT_F64 && c->tile && c->n) {           // the tile kernel's fp32 image of an fp64 cloud, written by finalize
+      RES(c, c->rec32, c->n * sizeof(RecF));
+      c->stb.shadow32 = (RecF*)c->rec32.p;
+    }
     uint32_t* occ = (uint32_t*)c->counter.p + 8;
     c->stb.occupied = c->adaptive ? c->stb.block_count : nullptr;     // block_count is dead once block_start exists
     const bool verify = guessed && iter == 0;
@@ -300,6 +309,12 @@ int rebuild(pt_ctx* c) {
   }
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   HIPCHK(c, hipGetLastError());
+  if (c->src_type == PT_F64 && c->stb.shadow32) {
+    double amax = 0.0;                                          // largest |coordinate| a source point can have: the grid box's corners
+    for (int a = 0; a < 3; ++a) amax = std::max(amax, std::max(std::fabs(c->gp.bbmin[a]), std::fabs(c->gp.bbmin[a] + c->gp.dim[a] * c->gp.h)));
+    c->e_src = (float)(amax * 5.9604645e-8 * 1.000001);         // 2^-24 relative rounding, rounded up
+    c->rec32_valid = std::isfinite(c->e_src);
+  }
   c->built = true;
   c->st.n_source = c->n;
   c->st.grid_dim[0] = c->gp.dim[0]; c->st.grid_dim[1] = c->gp.dim[1]; c->st.grid_dim[2] = c->gp.dim[2];
@@ -355,45 +370,52 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
   RES(c, c->todo, std::max<size_t>(m, 1) * sizeof(uint32_t));
   { int r = make_tables(c, c->ttb_mem, c->ttb, (uint32_t)c->gp.nblocks, m, recsize(ttype)); if (r != PT_OK) return r; }
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  // A cloud whose occupied cells stay far above rho even after refinement (blobs, strong density contrast) overflows
+  // most tile regions: measured on the clustered generator the group kernel alone is ~8 % faster than tile kernel +
+  // hand-over, so the automatic mode goes straight to it.
+  const bool contrast = contrast_last(c);
+  const bool use_tile = c->tile && !contrast && !bound2_dev && m && k <= PT_TILE_MAX_K && (ttype == PT_F32 || c->rec32_valid);
+  // The tile kernel over all blocks (+ the large geometry for the blocks the small one had to pass on); what it cannot
+  // settle is on the todo list afterwards.  fp64 clouds: the LDS image is the fp32 shadow of the sorted records, the exact
+  // 32-byte records are fetched for the few candidates that reach the ranking pass.
+  auto tile_launches = [&](const RecF* src32, const RecF* tgt32, const RecD* src64, const RecD* tgt64, uint32_t* todo_n) -> int {
+    const double cells = (double)c->gp.dim[0] * c->gp.dim[1] * c->gp.dim[2];
+    // regions (10^3 cells) that fit the small capacity with headroom run the two-workgroups-per-CU geometry
+    const int tile_small = c->tile == 2 || (c->tile == 1 && (double)c->n / cells * 1000.0 * 1.05 <= (double)(k <= 8 ? PT_TILE_CAP_SMALL_8 : PT_TILE_CAP_SMALL_16));
+    HIPCHK(c, hipMemsetAsync(todo_n, 0, 4, c->stream));
+    const Attr* battr = br ? (const Attr*)c->attr.p : nullptr;
+    const bool second_chance = tile_small && k <= 16;         // small geometry: over-budget blocks get the large one
+    uint32_t* retry_n = (uint32_t*)c->counter.p + 5;
+    if (second_chance) {
+      HIPCHK(c, hipMemsetAsync(retry_n, 0, 4, c->stream));
+      RES(c, c->retry, (size_t)c->gp.nblocks * sizeof(uint32_t));
+    }
+    pt_launch_knn_tile(c->gp, src32, (const uint32_t*)c->cell_start.p, tgt32, c->ttb.block_start, k, idx_dev, d2_dev, (uint32_t*)c->todo.p, todo_n,
+                       tile_small, battr, (uint32_t)c->n_total, br ? br->mode : 0, br ? br->rgb_out : nullptr, br ? br->nrm_out : nullptr, nullptr, 0,
+                       second_chance ? (uint32_t*)c->retry.p : nullptr, retry_n, src64, tgt64, c->e_src, c->stream);
+    if (second_chance) {
+      HIPCHK(c, hipMemcpyAsync(c->h_counter + 5, retry_n, 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));            // (one short read-back; usually 0 blocks and no launch)
+      if (c->h_counter[5])
+        pt_launch_knn_tile(c->gp, src32, (const uint32_t*)c->cell_start.p, tgt32, c->ttb.block_start, k, idx_dev, d2_dev, (uint32_t*)c->todo.p, todo_n,
+                           0, battr, (uint32_t)c->n_total, br ? br->mode : 0, br ? br->rgb_out : nullptr, br ? br->nrm_out : nullptr,
+                           (const uint32_t*)c->retry.p, c->h_counter[5], nullptr, nullptr, src64, tgt64, c->e_src, c->stream);
+    }
+    return PT_OK;
+  };
+  uint32_t* todo_n = (uint32_t*)c->counter.p + 4;
   if (ttype == PT_F32) {
     const float* x = (const float*)txyz;
     // targets only need to be grouped by block (tile kernel) -- the cell-level pass is skipped
     const RecF* tsorted = pt_launch_grid_sort<float, RecF>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecF*)c->trec.p, (RecF*)c->trec_tmp.p, nullptr, c->ttb, false, c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    // A cloud whose occupied cells stay far above rho even after refinement (blobs, strong density contrast) overflows
-    // most tile regions: measured on the clustered generator the group kernel alone is ~8 % faster than tile kernel +
-    // hand-over, so the automatic mode goes straight to it.
-    const bool contrast = c->tile == 1 && c->adaptive && c->st.rho_occupied > 1.5 * c->rho;
-    if (c->tile && !contrast && !bound2_dev && m && k <= PT_TILE_MAX_K) {
-      // regions (10^3 cells) that fit the small capacity with headroom run the two-workgroups-per-CU geometry
-      const double cells = (double)c->gp.dim[0] * c->gp.dim[1] * c->gp.dim[2];
-      const int tile_small = c->tile == 2 || (c->tile == 1 && (double)c->n / cells * 1000.0 * 1.05 <= (double)(k <= 8 ? PT_TILE_CAP_SMALL_8 : PT_TILE_CAP_SMALL_16));
-      uint32_t* todo_n = (uint32_t*)c->counter.p + 4;
-      HIPCHK(c, hipMemsetAsync(todo_n, 0, 4, c->stream));
-      const Attr* battr = br ? (const Attr*)c->attr.p : nullptr;
-      const bool second_chance = tile_small && k <= 16;         // small geometry: over-budget blocks get the large one
-      uint32_t* retry_n = (uint32_t*)c->counter.p + 5;
-      if (second_chance) {
-        HIPCHK(c, hipMemsetAsync(retry_n, 0, 4, c->stream));
-        RES(c, c->retry, (size_t)c->gp.nblocks * sizeof(uint32_t));
-      }
-      pt_launch_knn_tile(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, c->ttb.block_start, k, idx_dev, d2_dev,
-                         (uint32_t*)c->todo.p, todo_n, tile_small, battr, (uint32_t)c->n_total, br ? br->mode : 0,
-                         br ? br->rgb_out : nullptr, br ? br->nrm_out : nullptr, nullptr, 0, second_chance ? (uint32_t*)c->retry.p : nullptr,
-                         retry_n, c->stream);
-      if (second_chance) {
-        HIPCHK(c, hipMemcpyAsync(c->h_counter + 5, retry_n, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));            // (one short read-back; usually 0 blocks and no launch)
-        if (c->h_counter[5])
-          pt_launch_knn_tile(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, c->ttb.block_start, k, idx_dev, d2_dev,
-                             (uint32_t*)c->todo.p, todo_n, 0, battr, (uint32_t)c->n_total, br ? br->mode : 0, br ? br->rgb_out : nullptr,
-                             br ? br->nrm_out : nullptr, (const uint32_t*)c->retry.p, c->h_counter[5], nullptr, nullptr, c->stream);
-      }
+    if (use_tile) {
+      { int r = tile_launches((const RecF*)c->rec.p, tsorted, nullptr, nullptr, todo_n); if (r != PT_OK) return r; }
       pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, nullptr, idx_dev, d2_dev,
                           (const uint32_t*)c->todo.p, todo_n, c->stream);
       if (br)   // the targets the tile kernel handed over get their blend from the lists the group kernel just wrote
-        pt_launch_blend_list((const uint32_t*)c->todo.p, todo_n, m, tsorted, idx_dev, d2_dev, k, br->mode, (const Attr*)c->attr.p, (uint32_t)c->n_total,
-                             br->rgb_out, br->nrm_out, c->stream);
+        pt_launch_blend_list<RecF>((const uint32_t*)c->todo.p, todo_n, m, tsorted, idx_dev, d2_dev, k, br->mode, (const Attr*)c->attr.p,
+                                   (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
       HIPCHK(c, hipMemcpyAsync(c->h_counter + 4, todo_n, 4, hipMemcpyDeviceToHost, c->stream));
     } else {
       pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, bound2_dev, idx_dev, d2_dev,
@@ -404,9 +426,19 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     const double* x = (const double*)txyz;
     const RecD* tsorted = pt_launch_grid_sort<double, RecD>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecD*)c->trec.p, (RecD*)c->trec_tmp.p, nullptr, c->ttb, false, c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, bound2_dev, idx_dev, d2_dev,
-                        nullptr, nullptr, c->stream);
-    if (br) pt_launch_blend(idx_dev, d2_dev, m, k, br->mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
+    if (use_tile) {
+      { int r = tile_launches((const RecF*)c->rec32.p, nullptr, (const RecD*)c->rec.p, tsorted, todo_n); if (r != PT_OK) return r; }
+      pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, nullptr, idx_dev, d2_dev,
+                          (const uint32_t*)c->todo.p, todo_n, c->stream);
+      if (br)
+        pt_launch_blend_list<RecD>((const uint32_t*)c->todo.p, todo_n, m, tsorted, idx_dev, d2_dev, k, br->mode, (const Attr*)c->attr.p,
+                                   (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
+      HIPCHK(c, hipMemcpyAsync(c->h_counter + 4, todo_n, 4, hipMemcpyDeviceToHost, c->stream));
+    } else {
+      pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, bound2_dev, idx_dev, d2_dev,
+                          nullptr, nullptr, c->stream);
+      if (br) pt_launch_blend(idx_dev, d2_dev, m, k, br->mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
+    }
   }
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, hipGetLastError());
@@ -423,7 +455,7 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     c->st.ms_query = b;
     c->st.ms_kernel[6] = a;
     c->st.ms_kernel[7] = b;
-    c->st.n_leftover = (c->tile && !contrast_last(c) && !bound2_dev && m && k <= PT_TILE_MAX_K && ttype == PT_F32) ? c->h_counter[4] : 0;
+    c->st.n_leftover = use_tile ? c->h_counter[4] : 0;
   }
   return PT_OK;
 }
@@ -497,7 +529,7 @@ void pt_ctx_destroy(pt_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in_xyz, &c->in_gidx, &c->attr, &c->rec, &c->rec_tmp, &c->cell_start, &c->stb_mem, &c->t_xyz, &c->t_gidx, &c->trec,
-                   &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr, &c->retry};
+                   &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr, &c->retry, &c->rec32};
   for (DevBuf* b : all) release(c, *b);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);

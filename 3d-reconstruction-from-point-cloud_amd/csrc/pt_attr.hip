@@ -197,8 +197,9 @@ __global__ __launch_bounds__(WG) void blend_weighted_kernel(const uint32_t* __re
 }
 
 // the same for the targets on a list of positions in the sorted target array (what the tile kernel left to the group kernel)
+template <class Rec>
 __global__ __launch_bounds__(WG) void blend_list_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_n,
-                                                        const RecF* __restrict__ tgt, const uint32_t* __restrict__ idx, const double* __restrict__ d2,
+                                                        const Rec* __restrict__ tgt, const uint32_t* __restrict__ idx, const double* __restrict__ d2,
                                                         int k, int mode, const Attr* __restrict__ attr, uint32_t n_attr, float* __restrict__ rgb_out,
                                                         float* __restrict__ nrm_out) {
   const uint32_t i = blockIdx.x * WG + threadIdx.x;
@@ -368,11 +369,16 @@ void pt_launch_blend_weighted(const uint32_t* idx, const double* w, uint32_t m, 
   if (!m) return;
   hipLaunchKernelGGL(blend_weighted_kernel, grid_for(m), dim3(WG), 0, s, idx, w, m, k, attr, n_attr, rgb_out, nrm_out);
 }
-void pt_launch_blend_list(const uint32_t* list, const uint32_t* list_n, uint32_t m_max, const RecF* tgt, const uint32_t* idx, const double* d2, int k,
+template <class Rec>
+void pt_launch_blend_list(const uint32_t* list, const uint32_t* list_n, uint32_t m_max, const Rec* tgt, const uint32_t* idx, const double* d2, int k,
                           int mode, const Attr* attr, uint32_t n_attr, float* rgb_out, float* nrm_out, hipStream_t s) {
   if (!m_max) return;
-  hipLaunchKernelGGL(blend_list_kernel, grid_for(m_max), dim3(WG), 0, s, list, list_n, tgt, idx, d2, k, mode, attr, n_attr, rgb_out, nrm_out);
+  hipLaunchKernelGGL(blend_list_kernel<Rec>, grid_for(m_max), dim3(WG), 0, s, list, list_n, tgt, idx, d2, k, mode, attr, n_attr, rgb_out, nrm_out);
 }
+template void pt_launch_blend_list<RecF>(const uint32_t*, const uint32_t*, uint32_t, const RecF*, const uint32_t*, const double*, int, int, const Attr*,
+                                         uint32_t, float*, float*, hipStream_t);
+template void pt_launch_blend_list<RecD>(const uint32_t*, const uint32_t*, uint32_t, const RecD*, const uint32_t*, const double*, int, int, const Attr*,
+                                         uint32_t, float*, float*, hipStream_t);
 template <class T>
 void pt_launch_pca(const uint32_t* idx, uint32_t m, int k, const T* x, const T* y, const T* z, uint32_t n, const Attr* attr, float* nrm_out,
                    hipStream_t s) {

@@ -456,9 +456,15 @@ __global__ __launch_bounds__(WG) void hist_bid_kernel(const uint16_t* __restrict
 // ---- finalize: counting sort of one 8x8x8-cell block by local cell, in LDS -------------------------
 constexpr int FWG = 512;        // finalize workgroup: one thread per local cell in the scan
 constexpr int FITEMS = 12;      // records a thread keeps in registers: blocks up to 6144 points are read once
+__device__ inline void put_shadow(RecF* shadow, uint32_t pos, double x, double y, double z) {
+  RecF v;
+  v.x = (float)x; v.y = (float)y; v.z = (float)z; v.id = pos;      // rounded coordinates + where the exact record lives
+  shadow[pos] = v;
+}
 template <class Rec>
 __global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ in, Rec* __restrict__ out, GridParams gp,
-                                                       const uint32_t* __restrict__ block_start, uint32_t* cell_start, uint32_t* occupied) {
+                                                       const uint32_t* __restrict__ block_start, uint32_t* cell_start, uint32_t* occupied,
+                                                       RecF* __restrict__ shadow) {
   constexpr int FSTAGE = 64 * 1024 / (int)sizeof(Rec);        // records of a block that fit the 64-KB output stage
   static_assert(FSTAGE <= FWG * FITEMS, "staged blocks are register-resident blocks");
   __shared__ uint32_t cnt[PT_BLOCK_CELLS];
@@ -535,19 +541,29 @@ __global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ i
       if (i < e) stage[atomicAdd(&cnt[lc[j]], 1u)] = r[j];
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < e - s; i += FWG) out[s + i] = stage[i];
+    for (uint32_t i = threadIdx.x; i < e - s; i += FWG) {
+      const Rec v = stage[i];
+      out[s + i] = v;
+      if (shadow) put_shadow(shadow, s + i, (double)v.x, (double)v.y, (double)v.z);
+    }
   } else if (in_regs) {
 #pragma unroll
     for (int j = 0; j < FITEMS; ++j) {
       const uint32_t i = s + j * FWG + threadIdx.x;
-      if (i < e) out[s + atomicAdd(&cnt[lc[j]], 1u)] = r[j];
+      if (i < e) {
+        const uint32_t pos = s + atomicAdd(&cnt[lc[j]], 1u);
+        out[pos] = r[j];
+        if (shadow) put_shadow(shadow, pos, (double)r[j].x, (double)r[j].y, (double)r[j].z);
+      }
     }
   } else {
     for (uint32_t i = s + threadIdx.x; i < e; i += FWG) {   // oversized block: second read (mostly L2)
       const Rec v = in[i];
       int cx, cy, cz;
       pt_cell_of(gp, v, cx, cy, cz);
-      out[s + atomicAdd(&cnt[pt_local_cell(cx, cy, cz)], 1u)] = v;
+      const uint32_t pos = s + atomicAdd(&cnt[pt_local_cell(cx, cy, cz)], 1u);
+      out[pos] = v;
+      if (shadow) put_shadow(shadow, pos, (double)v.x, (double)v.y, (double)v.z);
     }
   }
 }
@@ -645,7 +661,7 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
                          tb.tile_first1, 1, tb.cursor2);
     mark(4);
     blocked = tmp;
-    if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, blocked, out_final, gp, tb.block_start, cell_start, tb.occupied);
+    if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, blocked, out_final, gp, tb.block_start, cell_start, tb.occupied, tb.shadow32);
     mark(5);
     return do_finalize ? out_final : tmp;
   }
@@ -688,7 +704,7 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
     hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS_S, SW>), dim3(ntiles2), dim3(SW), 0, s, rl, tmp, gp, b2, tb.start1, tb.tile_first2,
                        (int)nmacro, tb.cursor2);
   mark(4);
-  if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start, tb.occupied);
+  if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start, tb.occupied, tb.shadow32);
   mark(5);
   return do_finalize ? out_final : tmp;
 }

@@ -19,6 +19,7 @@ struct SortTables {
   uint32_t* chunk_hist;  // [nchunks][nbins1]   per-chunk pass-1 histograms, then per-chunk bin cursors
   uint32_t* chunk_gsum;  // [ceil(nchunks/64)][nbins1]
   uint32_t* occupied;    // optional [nblocks]: non-empty cells of every block, written by finalize (may alias block_count)
+  RecF* shadow32;        // optional [npoints] (fp64 clouds): fp32-rounded copy of the sorted records, id = sorted position (tile kernel's LDS image)
   uint16_t* bid;         // [npoints] (two-level sorts): block-in-macro of every record as pass 1 placed it -- what pass 2's histogram reads
   hipEvent_t* ev;        // optional [6]: start, after hist1, scatter1, hist2+scan, scatter2, finalize (null = no timing)
 };
@@ -60,7 +61,7 @@ constexpr int PT_TILE_MAX_K = 32;      // beyond this the group kernel answers e
 void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* cell_start, const RecF* tgt, const uint32_t* tblock_start,
                         int k, uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int geometry, const Attr* attr, uint32_t n_attr,
                         int mode, float* rgb_out, float* nrm_out, const uint32_t* blocks, uint32_t nblocks_listed, uint32_t* retry,
-                        uint32_t* retry_n, hipStream_t s);
+                        uint32_t* retry_n, const RecD* src_exact, const RecD* tgt_exact, float e_src, hipStream_t s);
 void pt_launch_merge(const uint32_t* idx_lists, const double* d2_lists, int g, uint32_t m, int k, uint32_t* idx_out,
                      double* d2_out, hipStream_t s);
 template <class T>
@@ -82,7 +83,8 @@ void pt_launch_aos_split(const void* aos, uint32_t n, double* x, double* y, doub
 void pt_launch_pack_attr(const uint8_t* rgb, const float* nrm, uint32_t n, Attr* attr, hipStream_t s);
 void pt_launch_blend_weighted(const uint32_t* idx, const double* w, uint32_t m, int k, const Attr* attr, uint32_t n_attr, float* rgb_out,
                               float* nrm_out, hipStream_t s);
-void pt_launch_blend_list(const uint32_t* list, const uint32_t* list_n, uint32_t m_max, const RecF* tgt, const uint32_t* idx, const double* d2, int k,
+template <class Rec>
+void pt_launch_blend_list(const uint32_t* list, const uint32_t* list_n, uint32_t m_max, const Rec* tgt, const uint32_t* idx, const double* d2, int k,
                           int mode, const Attr* attr, uint32_t n_attr, float* rgb_out, float* nrm_out, hipStream_t s);
 void pt_launch_blend(const uint32_t* idx, const double* d2, uint32_t m, int k, int mode, const Attr* attr, uint32_t n_attr,
                      float* rgb_out, float* nrm_out, hipStream_t s);

@@ -495,12 +495,18 @@ struct TileBlend { const Attr* attr; uint32_t n_attr; int mode; float* rgb_out; 
 // Second chance for blocks whose region is over this geometry's LDS budget but within the large geometry's: their ids go
 // to `retry` (retry != null), and a second launch (blocks != null: blockIdx.x indexes that list) takes them.
 struct TileBlocks { const uint32_t* blocks; uint32_t* retry; uint32_t* retry_n; uint32_t retry_cap; };
+// fp64 clouds (DBL): the LDS image and the two fp32 passes work on fp32-ROUNDED coordinates (the build's shadow records,
+// whose id field is the sorted position), under a bound widened by the rounding; pass 3 fetches the exact 32-byte
+// records of the queued candidates by position.  src / tgt: the exact records; e_src: largest |coordinate| rounding
+// error of a source point (2^-24 * largest |coordinate| of the cloud's bounding box).
+struct TileDouble { const RecD* src; const RecD* tgt; float e_src; };
 
-template <int K, int TILE_CAP, int TWG, bool WIDE = false, bool BLEND = false>
+template <int K, int TILE_CAP, int TWG, bool WIDE = false, bool BLEND = false, bool DBL = false>
 __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(GridParams gp, const RecF* __restrict__ src, const uint32_t* __restrict__ cs,
                                                         const RecF* __restrict__ tgt, const uint32_t* __restrict__ tblock_start, int k,
                                                         uint32_t* __restrict__ out_idx, double* __restrict__ out_d2,
-                                                        uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_n, TileBlend bl, TileBlocks tb) {
+                                                        uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_n, TileBlend bl, TileBlocks tb,
+                                                        TileDouble dd) {
   constexpr int NW = TWG / 64;
   constexpr int TILE_QUADS = TWG / 4;
   constexpr int TILE_QCAP = TileQ<K, WIDE>::CAP, TILE_LCAP = TileQ<K, WIDE>::LCAP;
@@ -664,8 +670,13 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
     const bool active = t < te;                                        // whole quads are active or not
     RecF tr;
     tr.x = tr.y = tr.z = 0.f; tr.id = 0;
-    if (active) tr = tgt[t];
-    const double q[3] = {(double)tr.x, (double)tr.y, (double)tr.z};
+    double q[3] = {0.0, 0.0, 0.0};
+    if constexpr (DBL) {
+      if (active) { const RecD td = dd.tgt[t]; q[0] = td.x; q[1] = td.y; q[2] = td.z; tr.x = (float)td.x; tr.y = (float)td.y; tr.z = (float)td.z; tr.id = td.id; }
+    } else {
+      if (active) tr = tgt[t];
+      q[0] = (double)tr.x; q[1] = (double)tr.y; q[2] = (double)tr.z;
+    }
     double u[3];
     int cc[3];
 #pragma unroll
@@ -727,7 +738,15 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
 #pragma unroll
       for (int j = 1; j < K; ++j) kv = (j == k - 1) ? l32[j] : kv;
     }
-    const float thr = kth_bound32(kv);
+    float thr = kth_bound32(kv);
+    if constexpr (DBL) {
+      // Rounded coordinates move every difference by at most E per axis (source + target rounding), i.e. every distance
+      // by at most sqrt(3) E: k candidates lie within sqrt(kv') + sqrt(3) E of the target, so the true top k do, and
+      // their rounded distances are within another sqrt(3) E.  (1.0000005 covers sqrtf's rounding.)
+      const float e_t = 5.9604645e-8f * fmaxf(fmaxf(fabsf(tr.x), fabsf(tr.y)), fabsf(tr.z));
+      const float r = sqrtf(thr) * 1.0000005f + 3.4642f * (dd.e_src + e_t) * 1.000001f;
+      thr = r * r * 1.0000039f + 1e-30f;
+    }
 #if defined(PT_ABLATE) && PT_ABLATE == 2
     if (thr >= 0.f) continue;                       // timing-only build: staging + pass 1 (results are garbage)
 #endif
@@ -801,8 +820,8 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
         const uint32_t seg = (uint32_t)(e >= p1) + (uint32_t)(e >= p2) + (uint32_t)(e >= p3);
         const uint32_t off = e - (seg == 0 ? 0u : (seg == 1 ? p1 : (seg == 2 ? p2 : p3)));
         const RecF r = lrec[queue[((threadIdx.x & ~3u) + seg) * (TILE_LCAP + 1) + off]];
-        od[j] = dist2(q, r);
-        oi[j] = r.id;
+        if constexpr (DBL) { const RecD rd = dd.src[r.id]; od[j] = dist2(q, rd); oi[j] = rd.id; }     // r.id: sorted position of the exact record
+        else { od[j] = dist2(q, r); oi[j] = r.id; }
       }
     }
     // Ranking counts, for each of my entries, the queue entries with a smaller distance.  Equal distances (rare) leave
@@ -970,23 +989,29 @@ template void pt_launch_knn<RecD>(const GridParams&, const RecD*, const uint32_t
 // geometry 1 = the two-workgroups-per-CU geometry (regions of <= PT_TILE_CAP_SMALL_* records), 0 = large.  With `attr` the
 // neighbours' attributes are blended in the same pass (rgb_out / nrm_out rows of the settled targets only).  `retry`:
 // blocks over the small budget but within the large one are listed there instead of going to `todo`; `blocks`: run over
-// such a list (nblocks_listed entries) instead of every block.
+// such a list (nblocks_listed entries) instead of every block.  src_exact / tgt_exact (fp64 clouds): `src` is then the fp32
+// shadow of the sorted records and `tgt` is unused.
 void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* cell_start, const RecF* tgt, const uint32_t* tblock_start, int k,
                         uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int geometry, const Attr* attr, uint32_t n_attr, int mode,
                         float* rgb_out, float* nrm_out, const uint32_t* blocks, uint32_t nblocks_listed, uint32_t* retry, uint32_t* retry_n,
-                        hipStream_t s) {
+                        const RecD* src_exact, const RecD* tgt_exact, float e_src, hipStream_t s) {
   const uint32_t nb = blocks ? nblocks_listed : (uint32_t)gp.nblocks;
   if (!nb) return;
   const TileBlend bl{attr, n_attr, mode, rgb_out, nrm_out};
   const TileBlocks tbk{blocks, retry, retry_n, (uint32_t)PT_TILE_CAP_LARGE};
-#define PT_TILE_LAUNCH(KK, CAP, TH, WD)                                                                                                          \
-  do {                                                                                                                                           \
-    if (attr)                                                                                                                                    \
-      hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH, WD, true>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, \
-                         out_d2, todo, todo_n, bl, tbk);                                                                                         \
-    else                                                                                                                                         \
-      hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH, WD, false>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k,         \
-                         out_idx, out_d2, todo, todo_n, bl, tbk);                                                                                \
+  const TileDouble dd{src_exact, tgt_exact, e_src};
+#define PT_TILE_LAUNCH1(KK, CAP, TH, WD, BL, DB)                                                                                              \
+  hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH, WD, BL, DB>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, \
+                     out_d2, todo, todo_n, bl, tbk, dd)
+#define PT_TILE_LAUNCH(KK, CAP, TH, WD)                                   \
+  do {                                                                    \
+    if (src_exact) {                                                      \
+      if (attr) PT_TILE_LAUNCH1(KK, CAP, TH, WD, true, true);             \
+      else PT_TILE_LAUNCH1(KK, CAP, TH, WD, false, true);                 \
+    } else {                                                              \
+      if (attr) PT_TILE_LAUNCH1(KK, CAP, TH, WD, true, false);            \
+      else PT_TILE_LAUNCH1(KK, CAP, TH, WD, false, false);                \
+    }                                                                     \
   } while (0)
   const int small = geometry == 1;
   if (k > 24) PT_TILE_LAUNCH(32, PT_TILE_CAP_WIDE, 512, true);      // wide queue, 512 threads, one workgroup per CU
@@ -999,6 +1024,7 @@ void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* c
     else PT_TILE_LAUNCH(32, PT_TILE_CAP_LARGE, 768, false);
   }
 #undef PT_TILE_LAUNCH
+#undef PT_TILE_LAUNCH1
 }
 
 void pt_launch_merge(const uint32_t* idx_lists, const double* d2_lists, int g, uint32_t m, int k, uint32_t* idx_out, double* d2_out,
