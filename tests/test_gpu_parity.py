@@ -533,7 +533,7 @@ def test_fused_query_blend_matches_the_two_calls(pkg, oracle, k, mode, tile):
 
 
 def test_fused_query_blend_double_cloud_and_errors(pkg):
-    """fp64 clouds take the unfused route behind the same call (bit-identical to the two calls); inverse-d2 without a
+    """fp64 clouds behind the fused call: same neighbours as the two calls, blend within tolerance; inverse-d2 without a
     d2 buffer is refused."""
     import torch
     n, m, k, seed = 40000, 3000, 8, 0xD0
@@ -547,7 +547,9 @@ def test_fused_query_blend_double_cloud_and_errors(pkg):
         i1 = torch.empty_like(i0); d1 = torch.empty_like(d0); r1 = torch.empty_like(r0); n1 = torch.empty_like(n0)
         p.query_blend_resident_dev(k, pkg.BLEND_INV_D2, i1, d1, r1, n1)
         torch.cuda.synchronize()
-        assert torch.equal(i0, i1) and torch.equal(d0, d1) and torch.equal(r0, r1) and torch.equal(n0, n1)
+        assert torch.equal(i0, i1) and torch.equal(d0, d1)
+        # (fp64 clouds run the tile kernel too: the fused blend sums the same terms in another order)
+        assert float((r0 - r1).abs().max()) / 255 <= TOL and float((n0 - n1).abs().max()) <= TOL
         with pytest.raises(Exception):
             p.query_blend_resident_dev(k, pkg.BLEND_INV_D2, i1, None, r1, n1)
 
