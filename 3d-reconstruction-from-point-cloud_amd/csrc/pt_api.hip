@@ -313,7 +313,7 @@ int rebuild(pt_ctx* c) {
     double amax = 0.0;                                          // largest |coordinate| a source point can have: the grid box's corners
     for (int a = 0; a < 3; ++a) amax = std::max(amax, std::max(std::fabs(c->gp.bbmin[a]), std::fabs(c->gp.bbmin[a] + c->gp.dim[a] * c->gp.h)));
     c->e_src = (float)(amax * 5.9604645e-8 * 1.000001);         // 2^-24 relative rounding, rounded up
-    c->rec32_valid = std::isfinite(c->e_src);
+    c->rec32_valid = std::isfinite(c->e_src) && amax < 1e30;  // (coordinates an fp32 cannot hold: the group kernel answers)
   }
   c->built = true;
   c->st.n_source = c->n;

@@ -630,3 +630,14 @@ def test_caller_targets_made_resident(pkg, oracle):
         p.query_resident_dev(k, idx, d2)
         torch.cuda.synchronize()
         _check_exact((idx.cpu().numpy().view(np.uint32), d2.cpu().numpy()), want, "resident AoS targets")
+
+
+def test_double_cloud_with_coordinates_beyond_float_range(pkg, oracle):
+    """fp64 clouds whose coordinates an fp32 cannot hold (the tile kernel's fp32 shadow would be inf) still get exact answers."""
+    rng = np.random.default_rng(12)
+    src = rng.random((3, 20000)) * 1e39
+    tgt = rng.random((3, 500)) * 1e39
+    with pkg.PointsTransfer(device=0) as p:
+        p.build(src, xyz_type=pkg.F64)
+        got = p.query(tgt, 8, xyz_type=pkg.F64)
+    _check_exact(got, oracle.knn_bruteforce(src, tgt, 8), "huge coordinates")
