@@ -22,7 +22,9 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "Point.h"
@@ -120,19 +122,43 @@ int main(int argc, char** argv) {
   std::cout << "Draw triangles total time: " << t_blend << " seconds" << std::endl;   // here: attribute blend (no texture bake)
   t_task = clk::now();
 
-  {   // output: the mesh with transferred colour/normal
-    std::ofstream o(out_name);
+  {   // output: the mesh with transferred colour/normal.  Formatted in parallel (one chunk of records per thread, "%.9g" =
+      // what operator<< prints at precision 9), written in order.
+    std::ofstream o(out_name, std::ios::binary);
     o << "ply\nformat ascii 1.0\nelement vertex " << M << "\n"
       << "property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
       << "property float s\nproperty float t\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
       << "element face " << mesh.faces.size() / 3 << "\nproperty list uchar int vertex_indices\nend_header\n";
-    o.precision(9);
-    for (size_t i = 0; i < M; ++i) {
-      const Point& v = mesh.vertices[i];
-      o << v.x() << ' ' << v.y() << ' ' << v.z() << ' ' << nrm[3 * i] << ' ' << nrm[3 * i + 1] << ' ' << nrm[3 * i + 2] << ' ' << v.u() << ' '
-        << v.v() << ' ' << (int)rgb[3 * i] << ' ' << (int)rgb[3 * i + 1] << ' ' << (int)rgb[3 * i + 2] << '\n';   // float -> uchar truncates, as :100-102
-    }
-    for (size_t f = 0; f + 2 < mesh.faces.size(); f += 3) o << "3 " << mesh.faces[f] << ' ' << mesh.faces[f + 1] << ' ' << mesh.faces[f + 2] << '\n';
+    const size_t F = mesh.faces.size() / 3;
+    int nth = (int)std::thread::hardware_concurrency();
+    nth = std::max(1, std::min(nth, 64));
+    nth = (int)std::min<size_t>((size_t)nth, (M + F) / 20000 + 1);
+    std::vector<std::string> part((size_t)nth * 2);
+    auto format = [&](int t) {
+      char buf[256];
+      std::string& sv = part[(size_t)t];
+      const size_t v0 = M * (size_t)t / (size_t)nth, v1 = M * (size_t)(t + 1) / (size_t)nth;
+      sv.reserve((v1 - v0) * 96);
+      for (size_t i = v0; i < v1; ++i) {
+        const Point& v = mesh.vertices[i];
+        const int len = std::snprintf(buf, sizeof buf, "%.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %d %d %d\n", v.x(), v.y(), v.z(), (double)nrm[3 * i],
+                                      (double)nrm[3 * i + 1], (double)nrm[3 * i + 2], v.u(), v.v(), (int)rgb[3 * i], (int)rgb[3 * i + 1],
+                                      (int)rgb[3 * i + 2]);   // float -> uchar truncates, as :100-102
+        sv.append(buf, (size_t)len);
+      }
+      std::string& sf = part[(size_t)nth + (size_t)t];
+      const size_t f0 = F * (size_t)t / (size_t)nth, f1 = F * (size_t)(t + 1) / (size_t)nth;
+      sf.reserve((f1 - f0) * 28);
+      for (size_t f = f0; f < f1; ++f) {
+        const int len = std::snprintf(buf, sizeof buf, "3 %d %d %d\n", mesh.faces[3 * f], mesh.faces[3 * f + 1], mesh.faces[3 * f + 2]);
+        sf.append(buf, (size_t)len);
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nth; ++t) th.emplace_back(format, t);
+    format(0);
+    for (auto& t : th) t.join();
+    for (const std::string& sp : part) o.write(sp.data(), (std::streamsize)sp.size());
   }
   if (!nbr_name.empty()) {
     std::ofstream o(nbr_name, std::ios::binary);
