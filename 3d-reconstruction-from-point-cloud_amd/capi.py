@@ -22,7 +22,7 @@ SYMBOLS = [
     "pt_build_aos", "pt_build_soa", "pt_build_soa_indexed", "pt_set_attributes", "pt_build_synth", "pt_rebuild",
     "pt_num_source", "pt_query_aos", "pt_query_soa", "pt_targets_synth", "pt_targets_soa", "pt_targets_aos", "pt_num_targets", "pt_query_resident", "pt_query_blend_resident",
     "pt_resident_target_ids", "pt_resident_target_xyz", "pt_blend", "pt_blend_dev", "pt_blend_weighted", "pt_blend_weighted_dev", "pt_pca_normals",
-    "pt_pca_normals_dev", "pt_merge_candidates_dev", "pt_slab_need_dev", "pt_query_bounded_dev",
+    "pt_pca_normals_dev", "pt_merge_candidates_dev", "pt_slab_need_dev", "pt_pack_requests_dev", "pt_query_bounded_dev",
 ]
 
 
@@ -93,6 +93,7 @@ def lib():
         "pt_pca_normals_dev": (i32, [p, p, u64, i32, p]),
         "pt_merge_candidates_dev": (i32, [p, p, p, i32, u64, i32, p, p]),
         "pt_slab_need_dev": (i32, [p, p, i32, p, u64, i32, i32, p, i32, i32, p]),
+        "pt_pack_requests_dev": (i32, [p, p, i32, p, u64, i32, i32, p, i32, i32, p, p, p]),
         "pt_query_bounded_dev": (i32, [p, p, i32, p, u64, i32, p, p]),
     }
     assert sorted(sig) == sorted(SYMBOLS)

@@ -968,4 +968,26 @@ int pt_slab_need_dev(pt_ctx* c, const void* tgt_xyz_dev, int xyz_type, const dou
   return finish(c);
 }
 
+int pt_pack_requests_dev(pt_ctx* c, const void* tgt_xyz_dev, int xyz_type, const double* d2_dev, uint64_t m, int k, int slab_axis,
+                         const double* slab_bounds, int g, int my_slab, uint32_t* sel_out_dev, double* pkt_out_dev, uint32_t* count_out) {
+  if (!c) return PT_ERR_ARG;
+  if (xyz_type != PT_F32 && xyz_type != PT_F64) return fail(c, PT_ERR_UNSUPPORTED, "xyz_type %d not supported yet", xyz_type);
+  if (g < 1 || g > 52 || k < 1 || k > PT_MAX_K || slab_axis < 0 || slab_axis > 2 || my_slab < 0 || my_slab >= g) return fail(c, PT_ERR_ARG, "argument out of range");
+  if (!count_out || !slab_bounds || (m && (!tgt_xyz_dev || !d2_dev || !sel_out_dev || !pkt_out_dev))) return fail(c, PT_ERR_ARG, "null argument");
+  { int r = check_n(c, m, "m"); if (r) return r; }
+  HIPCHK(c, hipSetDevice(c->device));
+  RES(c, c->bounds, 65 * sizeof(double));
+  uint32_t* cnt = (uint32_t*)c->counter.p + 6;
+  HIPCHK(c, hipMemcpyAsync(c->bounds.p, slab_bounds, (size_t)(g + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(cnt, 0, 4, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));       // (slab_bounds is the caller's host memory)
+  if (xyz_type == PT_F32) { const float* x = (const float*)tgt_xyz_dev; pt_launch_request_pack<float>(x, x + m, x + 2 * m, d2_dev, (uint32_t)m, k, slab_axis, (const double*)c->bounds.p, g, my_slab, cnt, sel_out_dev, pkt_out_dev, c->stream); }
+  else { const double* x = (const double*)tgt_xyz_dev; pt_launch_request_pack<double>(x, x + m, x + 2 * m, d2_dev, (uint32_t)m, k, slab_axis, (const double*)c->bounds.p, g, my_slab, cnt, sel_out_dev, pkt_out_dev, c->stream); }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_counter + 6, cnt, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *count_out = c->h_counter[6];
+  return PT_OK;
+}
+
 }  // extern "C"

@@ -62,6 +62,9 @@ void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* c
                         int k, uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int geometry, const Attr* attr, uint32_t n_attr,
                         int mode, float* rgb_out, float* nrm_out, const uint32_t* blocks, uint32_t nblocks_listed, uint32_t* retry,
                         uint32_t* retry_n, const RecD* src_exact, const RecD* tgt_exact, float e_src, hipStream_t s);
+template <class T>
+void pt_launch_request_pack(const T* x, const T* y, const T* z, const double* d2, uint32_t m, int k, int axis, const double* bounds_dev, int g,
+                            int my_slab, uint32_t* count, uint32_t* sel, double* pkt, hipStream_t s);
 void pt_launch_merge(const uint32_t* idx_lists, const double* d2_lists, int g, uint32_t m, int k, uint32_t* idx_out,
                      double* d2_out, hipStream_t s);
 template <class T>

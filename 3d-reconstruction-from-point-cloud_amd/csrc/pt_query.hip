@@ -966,7 +966,44 @@ __global__ __launch_bounds__(WG) void slab_need_kernel(const T* __restrict__ x, 
   }
 }
 
+// slab_need + compaction in one pass: the targets that need another slab leave as request packets
+// {x, y, z, current k-th d2, bitmask of the slabs asked} (5 doubles) with their row in `sel`; *count is the number written
+// (order unspecified: whoever reserves a slot first).  The bitmask is exact in a double for g <= 52.
+template <class T>
+__global__ __launch_bounds__(WG) void request_pack_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z,
+                                                          const double* __restrict__ d2, uint32_t m, int k, int axis,
+                                                          const double* __restrict__ bounds, int g, int my_slab, uint32_t* __restrict__ count,
+                                                          uint32_t* __restrict__ sel, double* __restrict__ pkt) {
+  const uint32_t t = blockIdx.x * WG + threadIdx.x;
+  if (t >= m) return;
+  const double c = (double)(axis == 0 ? x[t] : (axis == 1 ? y[t] : z[t]));
+  const double kth = d2[(size_t)t * k + (k - 1)];
+  uint64_t mask = 0;
+  for (int s = 0; s < g; ++s) {
+    if (s == my_slab) continue;
+    const double lo = bounds[s], hi = bounds[s + 1];
+    const double gapd = c < lo ? lo - c : (c >= hi ? c - hi : 0.0);
+    if (gapd * gapd * (1.0 - 1e-12) <= kth) mask |= 1ull << s;       // same test as slab_need_kernel
+  }
+  if (!mask) return;
+  const uint32_t pos = atomicAdd(count, 1u);                         // (folded into one atomic per wave)
+  sel[pos] = t;
+  double* o = pkt + (size_t)pos * 5;
+  o[0] = (double)x[t]; o[1] = (double)y[t]; o[2] = (double)z[t]; o[3] = kth; o[4] = (double)mask;
+}
+
 }  // namespace
+
+template <class T>
+void pt_launch_request_pack(const T* x, const T* y, const T* z, const double* d2, uint32_t m, int k, int axis, const double* bounds_dev, int g,
+                            int my_slab, uint32_t* count, uint32_t* sel, double* pkt, hipStream_t s) {
+  if (!m) return;
+  hipLaunchKernelGGL(request_pack_kernel<T>, dim3((m + WG - 1) / WG), dim3(WG), 0, s, x, y, z, d2, m, k, axis, bounds_dev, g, my_slab, count, sel, pkt);
+}
+template void pt_launch_request_pack<float>(const float*, const float*, const float*, const double*, uint32_t, int, int, const double*, int, int,
+                                            uint32_t*, uint32_t*, double*, hipStream_t);
+template void pt_launch_request_pack<double>(const double*, const double*, const double*, const double*, uint32_t, int, int, const double*, int,
+                                             int, uint32_t*, uint32_t*, double*, hipStream_t);
 
 template <class Rec>
 void pt_launch_knn(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const Rec* tgt, uint32_t m, int k, const double* bound2,

@@ -101,6 +101,16 @@ class GpuSlabEngine:
             self.pt.slab_need_dev(xyz, self.xyz_type, d2, m, k, axis, bounds, my_slab, need)
         return need
 
+    def pack_requests(self, xyz, d2, k, axis, bounds, my_slab):
+        """slab_need and the selection of the crossing targets fused on the device: (rows [c] int64, packets [c, 5] f64)."""
+        m = xyz.shape[1]
+        if getattr(self, "_req_cap", 0) < m:                 # scratch sized for every target once, reused by later steps
+            self._req_sel = torch.empty((m,), dtype=torch.int32, device=self.device)
+            self._req_pkt = torch.empty((m, 5), dtype=torch.float64, device=self.device)
+            self._req_cap = m
+        c = self.pt.pack_requests_dev(xyz, self.xyz_type, d2, m, k, axis, bounds, my_slab, self._req_sel, self._req_pkt) if m else 0
+        return self._req_sel[:c].to(torch.int64), self._req_pkt[:c]
+
     def bounded_query(self, xyz, bound2, k):
         c = xyz.shape[1]
         idx = torch.empty((c, k), dtype=torch.int32, device=self.device)
@@ -141,20 +151,27 @@ def exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds, on_changed=N
     assert G <= 52, "the need bitmask travels as an exact integer in one f64"
     dev = idx.device
     m = xyz.shape[1]
-    need = engine.slab_need(xyz, d2, k, axis, bounds, me)                     # [G, m] u8
-    sel = torch.nonzero(need.any(dim=0)).flatten()                           # my targets that need another slab
-    c = int(sel.numel())
-    weights = (2.0 ** torch.arange(G, dtype=torch.float64, device=dev)).unsqueeze(1)
     # -- request packets: x, y, z, bound (current k-th d2), slab bitmask ------------------------------------------
+    if hasattr(engine, "pack_requests"):                                     # one device pass (GPU engine)
+        sel, mine_pkt = engine.pack_requests(xyz, d2, k, axis, bounds, me)
+        c = int(sel.numel())
+    else:                                                                    # the same in torch ops (oracle-backed engine of the CPU tests)
+        need = engine.slab_need(xyz, d2, k, axis, bounds, me)                 # [G, m] u8
+        sel = torch.nonzero(need.any(dim=0)).flatten()                       # my targets that need another slab
+        c = int(sel.numel())
+        weights = (2.0 ** torch.arange(G, dtype=torch.float64, device=dev)).unsqueeze(1)
+        mine_pkt = torch.empty((c, 5), dtype=torch.float64, device=dev)
+        if c:
+            mine_pkt[:, 0:3] = xyz[:, sel].t().to(torch.float64)
+            mine_pkt[:, 3] = d2[sel, k - 1]
+            mine_pkt[:, 4] = (need[:, sel].to(torch.float64) * weights).sum(dim=0)
     cmax = comm.max_int(c, dev)
     stats["crossing"] = c
     if cmax == 0:
         return stats
     pkt = torch.zeros((cmax, 5), dtype=torch.float64, device=dev)
     if c:
-        pkt[:c, 0:3] = xyz[:, sel].t().to(torch.float64)
-        pkt[:c, 3] = d2[sel, k - 1]
-        pkt[:c, 4] = (need[:, sel].to(torch.float64) * weights).sum(dim=0)
+        pkt[:c] = mine_pkt
     allreq = comm.all_gather(pkt)                                             # [G, cmax, 5]
     stats["bytes_gathered"] += allreq.numel() * 8
     # -- answer the requests addressed to my slab ---------------------------------------------------------------

@@ -245,6 +245,15 @@ class PointsTransfer:
         self._adopt_torch_stream()
         self._chk(self._L.pt_merge_candidates_dev(self._h, _ptr(idx_lists_dev), _ptr(d2_lists_dev), g, m, k, _ptr(idx_out_dev), _ptr(d2_out_dev)))
 
+    def pack_requests_dev(self, tgt_xyz_dev, xyz_type, d2_dev, m, k, slab_axis, slab_bounds, my_slab, sel_dev, pkt_dev):
+        """slab_need + selection in one pass: returns the number of request packets written to pkt_dev[:c] / sel_dev[:c]."""
+        self._adopt_torch_stream()
+        b = np.ascontiguousarray(slab_bounds, np.float64)
+        cnt = C.c_uint32(0)
+        self._chk(self._L.pt_pack_requests_dev(self._h, _ptr(tgt_xyz_dev), xyz_type, _ptr(d2_dev), m, k, slab_axis, _ptr(b), b.shape[0] - 1, my_slab,
+                                               _ptr(sel_dev), _ptr(pkt_dev), C.byref(cnt)))
+        return int(cnt.value)
+
     def slab_need_dev(self, tgt_xyz_dev, xyz_type, d2_dev, m, k, slab_axis, slab_bounds, my_slab, need_dev):
         self._adopt_torch_stream()
         b = np.ascontiguousarray(slab_bounds, np.float64)

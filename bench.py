@@ -201,7 +201,11 @@ def main():
         # k-NN and blend in one pass: the tile kernel gathers the attribute records as it settles each target
         pt.query_blend_resident_dev(k, pkg.BLEND_MEAN, idx, d2, rgb, nrm)
         st = pt.stats() if record else None       # HIP-event times of the build + home search, on the stream they ran on
+        if world > 1 and record:                   # (the exchange synchronises with the host anyway: its wall time is a fair phase time)
+            torch.cuda.synchronize(); tx = time.perf_counter()
         xs = sharding.exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds, on_changed=reblend)
+        if world > 1 and record:
+            torch.cuda.synchronize(); phase["exchange_merge_reblend"] = phase.get("exchange_merge_reblend", 0.0) + (time.perf_counter() - tx) * 1e3
         if with_pca:
             pt.pca_normals_dev(idx, m_loc, k, pnrm)     # BASELINE config 3: PCA normal estimation from the neighbours
         if record:

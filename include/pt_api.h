@@ -190,6 +190,12 @@ int  pt_merge_candidates_dev(pt_ctx*, const uint32_t* idx_lists_dev, const doubl
  * slab_bounds: G+1 ascending doubles on the host. */
 int  pt_slab_need_dev(pt_ctx*, const void* tgt_xyz_dev, int xyz_type, const double* d2_dev, uint64_t m, int k,
                       int slab_axis, const double* slab_bounds, int g, int my_slab, uint8_t* need_dev);
+/* pt_slab_need_dev and the selection of the targets that need another slab in one pass: those targets leave as request
+ * packets pkt_out[c][5] = {x, y, z, current k-th d2, bitmask of the slabs to ask (exact in a double: g <= 52)} with
+ * their rows in sel_out[c]; *count_out = c (host).  Both outputs must hold m entries; the order is unspecified. */
+int  pt_pack_requests_dev(pt_ctx*, const void* tgt_xyz_dev, int xyz_type, const double* d2_dev, uint64_t m, int k,
+                          int slab_axis, const double* slab_bounds, int g, int my_slab, uint32_t* sel_out_dev,
+                          double* pkt_out_dev, uint32_t* count_out);
 /* Bounded query for foreign targets: like pt_query_soa(on_device=1) but each target starts from the
  * radius bound2[t] (its current k-th squared distance; +inf = unbounded): only points with
  * d2 <= bound2[t] are returned. */
