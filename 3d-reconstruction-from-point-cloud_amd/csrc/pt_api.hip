@@ -147,6 +147,7 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
   tb.bid = bid_words ? (uint16_t*)p : nullptr;
   tb.occupied = nullptr;
   tb.shadow32 = nullptr;
+  tb.status = nullptr;
   tb.ev = nullptr;
   return PT_OK;
 }
@@ -185,8 +186,12 @@ void choose_grid(pt_ctx* c, const double mn[3], const double mx[3], double force
 template <class T, class Rec>
 int run_source_sort(pt_ctx* c, uint64_t* bbox6_verify) {
   const T* x = (const T*)c->in_xyz.p;
-  pt_launch_grid_sort<T, Rec>(c->gp, x, x + c->n, x + 2 * c->n, c->has_gidx ? (const uint32_t*)c->in_gidx.p : nullptr, (uint32_t)c->n,
-                              (Rec*)c->rec.p, (Rec*)c->rec_tmp.p, (uint32_t*)c->cell_start.p, c->stb, true, c->stream, bbox6_verify);
+  hipError_t e = hipSuccess;
+  c->stb.status = &e;
+  const Rec* r = pt_launch_grid_sort<T, Rec>(c->gp, x, x + c->n, x + 2 * c->n, c->has_gidx ? (const uint32_t*)c->in_gidx.p : nullptr, (uint32_t)c->n,
+                                             (Rec*)c->rec.p, (Rec*)c->rec_tmp.p, (uint32_t*)c->cell_start.p, c->stb, true, c->stream, bbox6_verify);
+  c->stb.status = nullptr;
+  if (!r) return fail(c, PT_ERR_HIP, "grid build: a launch of the sort failed: %s", hipGetErrorString(e));
   return PT_OK;
 }
 
@@ -267,7 +272,7 @@ int rebuild(pt_ctx* c) {
     const bool verify = guessed && iter == 0;
     if (verify) pt_launch_bbox_init((uint64_t*)c->bbox6.p, c->stream);
     uint64_t* bv = verify ? (uint64_t*)c->bbox6.p : nullptr;
-    if (c->src_type == PT_F32) run_source_sort<float, RecF>(c, bv); else run_source_sort<double, RecD>(c, bv);
+    { const int r = c->src_type == PT_F32 ? run_source_sort<float, RecF>(c, bv) : run_source_sort<double, RecD>(c, bv); if (r != PT_OK) return r; }
     if (verify) {
       HIPCHK(c, hipMemcpyAsync(c->h_bbox, c->bbox6.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -374,7 +379,11 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
   // most tile regions: measured on the clustered generator the group kernel alone is ~8 % faster than tile kernel +
   // hand-over, so the automatic mode goes straight to it.
   const bool contrast = contrast_last(c);
-  const bool use_tile = c->tile && !contrast && !bound2_dev && m && k <= PT_TILE_MAX_K && (ttype == PT_F32 || c->rec32_valid);
+  // (its fp32 pruning multiplies cell gaps by (float)(h*h): a cell side beyond ~1.8e19, or below ~1e-19, leaves fp32's range
+  //  and would prune -- or keep -- everything; such clouds are answered by the group kernel, which prunes in fp64)
+  const double h2d = c->gp.h * c->gp.h;
+  const bool h2_ok = h2d <= 3.0e38 && h2d >= 1.2e-38;
+  const bool use_tile = c->tile && !contrast && !bound2_dev && m && k <= PT_TILE_MAX_K && h2_ok && (ttype == PT_F32 || c->rec32_valid);
   // The tile kernel over all blocks (+ the large geometry for the blocks the small one had to pass on); what it cannot
   // settle is on the todo list afterwards.  fp64 clouds: the LDS image is the fp32 shadow of the sorted records, the exact
   // 32-byte records are fetched for the few candidates that reach the ranking pass.
@@ -408,6 +417,7 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     const float* x = (const float*)txyz;
     // targets only need to be grouped by block (tile kernel) -- the cell-level pass is skipped
     const RecF* tsorted = pt_launch_grid_sort<float, RecF>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecF*)c->trec.p, (RecF*)c->trec_tmp.p, nullptr, c->ttb, false, c->stream);
+    if (!tsorted) return fail(c, PT_ERR_HIP, "target binning: a launch of the sort failed: %s", hipGetErrorString(hipGetLastError()));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (use_tile) {
       { int r = tile_launches((const RecF*)c->rec.p, tsorted, nullptr, nullptr, todo_n); if (r != PT_OK) return r; }
@@ -425,6 +435,7 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
   } else {
     const double* x = (const double*)txyz;
     const RecD* tsorted = pt_launch_grid_sort<double, RecD>(c->gp, x, x + m, x + 2 * (size_t)m, nullptr, m, (RecD*)c->trec.p, (RecD*)c->trec_tmp.p, nullptr, c->ttb, false, c->stream);
+    if (!tsorted) return fail(c, PT_ERR_HIP, "target binning: a launch of the sort failed: %s", hipGetErrorString(hipGetLastError()));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (use_tile) {
       { int r = tile_launches((const RecF*)c->rec32.p, nullptr, (const RecD*)c->rec.p, tsorted, todo_n); if (r != PT_OK) return r; }

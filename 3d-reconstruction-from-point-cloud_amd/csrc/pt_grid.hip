@@ -115,7 +115,7 @@ __global__ __launch_bounds__(WG) void bbox_kernel(const T* __restrict__ x, const
   for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) {
     const double v[3] = {(double)x[i], (double)y[i], (double)z[i]};
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { mn[a] = fmin(mn[a], v[a]); mx[a] = fmax(mx[a], v[a]); }
+    for (int a = 0; a < 3; ++a) { mn[a] = (v[a] != v[a]) ? -INFINITY : fmin(mn[a], v[a]); mx[a] = fmax(mx[a], v[a]); }   // NaN: fmin / fmax would drop it
   }
   wg_bbox_commit(mn, mx, out6);
 }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(WG) void bbox_sample_kernel(const T* __restrict__ x
   for (uint64_t i = (uint64_t)blockIdx.x * span + threadIdx.x; i < n; i += (uint64_t)gridDim.x * span) {
     const double v[3] = {(double)x[i], (double)y[i], (double)z[i]};
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { mn[a] = fmin(mn[a], v[a]); mx[a] = fmax(mx[a], v[a]); }
+    for (int a = 0; a < 3; ++a) { mn[a] = (v[a] != v[a]) ? -INFINITY : fmin(mn[a], v[a]); mx[a] = fmax(mx[a], v[a]); }   // NaN: fmin / fmax would drop it
   }
   wg_bbox_commit(mn, mx, out6);
 }
@@ -315,6 +315,7 @@ __global__ __launch_bounds__(WG) void hist_chunk_kernel(Loader in, GridParams gp
   const uint32_t end = (uint32_t)min((uint64_t)n, base + span);
   using CT = decltype(in.load(0).x);                 // min / max in the cloud's own type: exact, and cheap for fp32
   CT tmn[3] = {(CT)INFINITY, (CT)INFINITY, (CT)INFINITY}, tmx[3] = {(CT)-INFINITY, (CT)-INFINITY, (CT)-INFINITY};
+  bool nan_seen = false;
   for (uint32_t i = (uint32_t)base + threadIdx.x; i < end; i += WG) {
     const auto r = in.load(i);
     atomicAdd(&hist[local_bin(bs, block_of_rec(gp, r))], 1u);
@@ -322,9 +323,11 @@ __global__ __launch_bounds__(WG) void hist_chunk_kernel(Loader in, GridParams gp
       tmn[0] = r.x < tmn[0] ? r.x : tmn[0]; tmx[0] = r.x > tmx[0] ? r.x : tmx[0];
       tmn[1] = r.y < tmn[1] ? r.y : tmn[1]; tmx[1] = r.y > tmx[1] ? r.y : tmx[1];
       tmn[2] = r.z < tmn[2] ? r.z : tmn[2]; tmx[2] = r.z > tmx[2] ? r.z : tmx[2];
+      nan_seen |= (r.x != r.x) | (r.y != r.y) | (r.z != r.z);          // the comparisons above ignore a NaN
     }
   }
   if (bbox6) {
+    if (nan_seen) tmn[0] = (CT)-INFINITY;                               // "not finite" for the host's check of the verified box
     double mn[3] = {(double)tmn[0], (double)tmn[1], (double)tmn[2]}, mx[3] = {(double)tmx[0], (double)tmx[1], (double)tmx[2]};
     wg_bbox_commit(mn, mx, bbox6);
   }
@@ -638,9 +641,13 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
   const uint32_t nmacro = nblocks / PT_MACRO_BLOCKS;
   const uint32_t ntiles = (n + TILE - 1) / TILE;
   PlanarLoader<T> pl{x, y, z, gidx};
-  auto mark = [&](int i) { if (tb.ev) (void)hipEventRecord(tb.ev[i], s); };
+  // every HIP call of the sort is checked: the first failure is kept, reported through tb.status and turns the result into nullptr
+  hipError_t first = hipSuccess;
+  auto ck = [&](hipError_t e) { if (first == hipSuccess && e != hipSuccess) first = e; };
+  auto done = [&](const Rec* r) -> const Rec* { ck(hipGetLastError()); if (tb.status) *tb.status = first; return first == hipSuccess ? r : nullptr; };
+  auto mark = [&](int i) { if (tb.ev) ck(hipEventRecord(tb.ev[i], s)); ck(hipGetLastError()); };     // (also collects launch errors of the phase just queued)
   mark(0);
-  (void)hipMemsetAsync(tb.block_count, 0, sizeof(uint32_t) * ((size_t)nblocks + 1), s);
+  ck(hipMemsetAsync(tb.block_count, 0, sizeof(uint32_t) * ((size_t)nblocks + 1), s));
   hipLaunchKernelGGL(single_segment_kernel, dim3(1), dim3(64), 0, s, n, TILE, tb.seg_start1, tb.tile_first1);
 
   const Rec* blocked = nullptr;   // records partitioned by block id
@@ -654,7 +661,7 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
                          tb.seg_start1, tb.tile_first1, 1, tb.block_count, tpw);
     }
     pt_launch_scan_u32(tb.block_count, tb.block_start, nblocks + 1, tb.scan_tmp, s);
-    (void)hipMemcpyAsync(tb.cursor2, tb.block_start, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s);
+    ck(hipMemcpyAsync(tb.cursor2, tb.block_start, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s));
     mark(1); mark(2); mark(3);
     if (n)
       hipLaunchKernelGGL((scatter_kernel<PlanarLoader<T>, ITEMS_S, SW>), dim3(ntiles), dim3(SW), 0, s, pl, tmp, gp, bs, tb.seg_start1,
@@ -663,7 +670,7 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
     blocked = tmp;
     if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, blocked, out_final, gp, tb.block_start, cell_start, tb.occupied, tb.shadow32);
     mark(5);
-    return do_finalize ? out_final : tmp;
+    return done(do_finalize ? out_final : tmp);
   }
   // two levels: planar -> out_final (by macro block) -> tmp (by block) -> out_final (by cell)
   const BinSpec b1{0, 9, (int)nmacro};
@@ -671,7 +678,7 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
   const int chunk_tiles = pt_sort_chunk_tiles(n, sizeof(Rec));
   const uint32_t nchunks = n ? (ntiles + chunk_tiles - 1) / chunk_tiles : 0;
   const uint32_t ngroups = (nchunks + COL_GROUP - 1) / COL_GROUP;
-  (void)hipMemsetAsync(tb.counts1, 0, sizeof(uint32_t) * (PT_MAXBINS + 1), s);
+  ck(hipMemsetAsync(tb.counts1, 0, sizeof(uint32_t) * (PT_MAXBINS + 1), s));
   if (n) {
     hipLaunchKernelGGL((hist_chunk_kernel<PlanarLoader<T>, ITEMS>), dim3(nchunks), dim3(WG), 0, s, pl, gp, b1, n, chunk_tiles, tb.chunk_hist,
                        bbox6_verify);
@@ -698,7 +705,7 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
                        tb.tile_first2, (int)nmacro, tb.block_count, tpw);
   }
   pt_launch_scan_u32(tb.block_count, tb.block_start, nblocks + 1, tb.scan_tmp, s);
-  (void)hipMemcpyAsync(tb.cursor2, tb.block_start, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s);
+  ck(hipMemcpyAsync(tb.cursor2, tb.block_start, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s));
   mark(3);
   if (n)
     hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS_S, SW>), dim3(ntiles2), dim3(SW), 0, s, rl, tmp, gp, b2, tb.start1, tb.tile_first2,
@@ -706,7 +713,7 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
   mark(4);
   if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start, tb.occupied, tb.shadow32);
   mark(5);
-  return do_finalize ? out_final : tmp;
+  return done(do_finalize ? out_final : tmp);
 }
 template const RecF* pt_launch_grid_sort<float, RecF>(const GridParams&, const float*, const float*, const float*, const uint32_t*, uint32_t, RecF*,
                                                       RecF*, uint32_t*, const SortTables&, bool, hipStream_t, uint64_t*);

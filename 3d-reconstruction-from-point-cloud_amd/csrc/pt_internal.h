@@ -21,6 +21,7 @@ struct SortTables {
   uint32_t* occupied;    // optional [nblocks]: non-empty cells of every block, written by finalize (may alias block_count)
   RecF* shadow32;        // optional [npoints] (fp64 clouds): fp32-rounded copy of the sorted records, id = sorted position (tile kernel's LDS image)
   uint16_t* bid;         // [npoints] (two-level sorts): block-in-macro of every record as pass 1 placed it -- what pass 2's histogram reads
+  hipError_t* status;    // optional: receives the first HIP error of the sort's launch path (hipSuccess otherwise)
   hipEvent_t* ev;        // optional [6]: start, after hist1, scatter1, hist2+scan, scatter2, finalize (null = no timing)
 };
 

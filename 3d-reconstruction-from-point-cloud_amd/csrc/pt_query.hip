@@ -558,11 +558,16 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
 #pragma unroll
       for (int i = 0; i < TILE_R; ++i) sum += cnt[i];
     }
-    if (ts == te) return;                               // no targets in this block (whole workgroup: ts, te are uniform)
+    // INVARIANT: ts and te are loaded from tblock_start[b] with b a function of blockIdx.x only, so they are the same in
+    // every lane of every wave of the workgroup: either ALL waves return here (and in the else branch below) or none does,
+    // and every wave that stays executes exactly one s_barrier in its branch -- the table waves the one between their scan
+    // halves, the other waves the one in the else branch -- before all of them meet again at the __syncthreads() below.
+    // (The test sits here rather than at the top so that the cell-table loads are in flight while ts / te arrive.)
+    if (ts == te) return;                               // no targets in this block
     const uint32_t incl = wave_incl_scan(sum);
     if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();                       // (waves 0 and 1 only meet here: see below)
+    __builtin_amdgcn_s_barrier();                       // all waves: waves >= 2 execute the matching s_barrier in the else branch
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const uint32_t w0 = wsum[0], w1 = wsum[1];
     uint32_t ex = (threadIdx.x >= 64 ? w0 : 0u) + incl - sum;
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
     }
     if (threadIdx.x == 0) { const uint32_t tot = w0 + w1; lstart[TILE_CELLS] = (uint16_t)(tot < 65535u ? tot : 65535u); ptotal = tot; }
   } else {
-    if (ts == te) return;
+    if (ts == te) return;                               // same workgroup-uniform test as above
     __builtin_amdgcn_s_barrier();                       // pairs with the barrier between the two table waves' scan halves
   }
   __syncthreads();
@@ -900,10 +905,14 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
           auto quad_sum = [](double v) { v += dpp_f64<DPP_QP_1032>(v); v += dpp_f64<DPP_QP_2301>(v); return v; };
           ws = quad_sum(ws); c0 = quad_sum(c0); c1 = quad_sum(c1); c2 = quad_sum(c2); n0 = quad_sum(n0); n1 = quad_sum(n1); n2 = quad_sum(n2);
           if (ws > 0.0) {
-            const double iw = 1.0 / ws;
-            c0 *= iw; c1 *= iw; c2 *= iw; n0 *= iw; n1 *= iw; n2 *= iw;
-            const double len = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
-            if (len >= 1e-12) { n0 /= len; n1 /= len; n2 /= len; }
+            // The sums above are fp64 (normals may cancel); the finishing touches use the hardware reciprocal and
+            // reciprocal square root (v_rcp_f64 / v_rsq_f64, ~2^-23 relative: two orders inside the 1e-5 bar) instead of
+            // four fp64 divisions and a square root, which were a third of this epilogue's instructions.
+            const double iw = __builtin_amdgcn_rcp(ws);
+            c0 *= iw; c1 *= iw; c2 *= iw;
+            const double l2 = n0 * n0 + n1 * n1 + n2 * n2;
+            const double sc = (l2 * iw * iw >= 1e-24) ? __builtin_amdgcn_rsq(l2) : iw;      // |mean normal| >= 1e-12: renormalise
+            n0 *= sc; n1 *= sc; n2 *= sc;
           }
           float* o = (ql == 0) ? bl.rgb_out : bl.nrm_out;
           if (ql < 2 && o) {

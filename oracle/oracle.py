@@ -41,6 +41,8 @@ def lib():
         L.pto_synth_xyz_f32.argtypes = [u64, u64, u64, u64, p]
         L.pto_synth_xyz_dist.argtypes = [u64, u64, i32, u64, u64, u64, u64, p]
         L.pto_synth_rgb.argtypes = [u64, u64, u64, p]
+        L.pto_synth_filter_boxes.restype = C.c_int64
+        L.pto_synth_filter_boxes.argtypes = [u64, u64, u64, i32, p, p, u64, p, p, p]
         L.pto_synth_nrm.argtypes = [u64, u64, u64, p]
         for f in ("pto_transformed_distance",):
             getattr(L, f).restype = C.c_double
@@ -87,6 +89,17 @@ def synth_xyz(seed, stream, n, i0=0, dist=0, n_total=0, m_total=0):
     else:
         lib().pto_synth_xyz_dist(seed, stream, dist, i0, n, n_total or n, m_total or n, _ptr(out))
     return out
+
+
+def synth_filter_boxes(seed, stream, n_total, lo, hi, cap=4_000_000):
+    """Stream the uniform generator over [0, n_total) and keep the points inside any of the boxes [lo[b], hi[b]) (float32
+    (nbox, 3) arrays): returns (xyz (3, c) float32, original indices (c,) uint32, box of each point (c,) int32), ascending index."""
+    lo = np.ascontiguousarray(lo, dtype=np.float32); hi = np.ascontiguousarray(hi, dtype=np.float32)
+    assert lo.shape == hi.shape and lo.ndim == 2 and lo.shape[1] == 3
+    xyz = np.empty((cap, 3), dtype=np.float32); idx = np.empty(cap, dtype=np.uint32); box = np.empty(cap, dtype=np.int32)
+    c = lib().pto_synth_filter_boxes(seed, stream, n_total, lo.shape[0], _ptr(lo), _ptr(hi), cap, _ptr(xyz), _ptr(idx), _ptr(box))
+    assert 0 <= c <= cap, "box filter: %d points for a capacity of %d" % (c, cap)
+    return np.ascontiguousarray(xyz[:c].T), idx[:c].copy(), box[:c].copy()
 
 
 def synth_rgb(seed, n, i0=0):

@@ -113,6 +113,50 @@ void pto_synth_xyz_dist(uint64_t seed, uint64_t stream, int dist, uint64_t i0, u
   }
 }
 
+/* Uniform generator, streamed and FILTERED: of the points i in [0, n_total) of (seed, stream) keep those inside any of
+ * `nbox` axis-aligned boxes [lo, hi) (lo / hi: [nbox][3]) -- what lets a test check a billion-point GPU answer against
+ * brute force without holding the cloud: every point is generated (same bits as pto_synth_xyz_f32), only a few thousand
+ * are kept.  x is hashed first and tested against the boxes' x-ranges, so most points cost one hash.  OpenMP over index
+ * chunks; the kept points come out in ascending index order.  Returns how many there were (may exceed `cap`: only the
+ * first cap are written), or -1 on allocation failure. */
+int64_t pto_synth_filter_boxes(uint64_t seed, uint64_t stream, uint64_t n_total, int nbox, const float* lo, const float* hi,
+                               uint64_t cap, float* out_xyz /* [cap][3] interleaved */, uint32_t* out_idx, int32_t* out_box) {
+  const uint64_t key = stream_key(seed, stream);
+  const uint64_t chunk = 1ull << 22;
+  const uint64_t nchunks = (n_total + chunk - 1) / chunk;
+  uint64_t* cnt = (uint64_t*)calloc(nchunks + 1, sizeof(uint64_t));
+  if (!cnt) return -1;
+  for (int pass = 0; pass < 2; ++pass) {           /* pass 0 counts per chunk, pass 1 writes at the scanned offsets */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t c = 0; c < (int64_t)nchunks; ++c) {
+      const uint64_t i0 = (uint64_t)c * chunk, i1 = i0 + chunk < n_total ? i0 + chunk : n_total;
+      uint64_t w = cnt[c], found = 0;
+      for (uint64_t i = i0; i < i1; ++i) {
+        const float x = u24(hash4(key, i, 0));
+        int hit = 0;
+        for (int b = 0; b < nbox; ++b) hit |= (x >= lo[3 * b] && x < hi[3 * b]);
+        if (!hit) continue;
+        const float y = u24(hash4(key, i, 1)), z = u24(hash4(key, i, 2));
+        for (int b = 0; b < nbox; ++b) {
+          if (x >= lo[3 * b] && x < hi[3 * b] && y >= lo[3 * b + 1] && y < hi[3 * b + 1] && z >= lo[3 * b + 2] && z < hi[3 * b + 2]) {
+            if (pass == 1 && w < cap) { out_xyz[3 * w] = x; out_xyz[3 * w + 1] = y; out_xyz[3 * w + 2] = z; out_idx[w] = (uint32_t)i; out_box[w] = b; }
+            ++w; ++found;
+            break;                                  /* boxes may overlap: the first one claims the point */
+          }
+        }
+      }
+      if (pass == 0) cnt[c] = found;
+    }
+    if (pass == 0) {
+      uint64_t run = 0;
+      for (uint64_t c = 0; c <= nchunks; ++c) { const uint64_t t = c < nchunks ? cnt[c] : 0; cnt[c] = run; run += t; }
+    }
+  }
+  const int64_t total = (int64_t)cnt[nchunks];
+  free(cnt);
+  return total;
+}
+
 /* colour = bytes 0,1,2 of h(seed,2,i,0); rgb is interleaved [n][3] */
 void pto_synth_rgb(uint64_t seed, uint64_t i0, uint64_t n, uint8_t* rgb) {
   const uint64_t key = stream_key(seed, 2);

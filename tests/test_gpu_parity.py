@@ -467,10 +467,20 @@ def test_full_size_c3_sampled_exactness(pkg, oracle):
         assert bool((d2[:, 1:] >= d2[:, :-1]).all())
         sel = torch.from_numpy(np.random.default_rng(1).choice(m, 5000, replace=False)).cuda()
         I = idx[sel].cpu().numpy().view(np.uint32); D = d2[sel].cpu().numpy()
+        pn = torch.empty((m, 3), dtype=torch.float32, device="cuda")
+        p.pca_normals_dev(idx, m, k, pn)                                     # config 3's PCA normals over ALL 10M targets
+        torch.cuda.synchronize()
+        PN = pn[sel].cpu().numpy()
+        assert bool(((pn.norm(dim=1) - 1).abs() < 1e-4).all())
     src = oracle.synth_xyz(seed, 0, n)
     tgt = oracle.synth_xyz(seed, 1, m)[:, sel.cpu().numpy()]
     wi, wd = oracle.KdTree(src).query(tgt, k)
     assert np.array_equal(I, wi) and np.array_equal(D, wd)
+    # the PCA of the sampled rows against the oracle (full-size cloud, the generator's stored normals orient the sign);
+    # uniform volume data is mostly NOT planar, so -- as in test_pca_matches_golden -- the well-conditioned rows are compared
+    want, plan = oracle.pca_normals(wi, src, oracle.synth_nrm(seed, n))
+    ok = plan < 0.2
+    assert ok.sum() > 100 and np.abs(PN[ok] - want[ok]).max() <= 1e-4
 
 
 def test_full_size_c4_two_kernels_agree(pkg):
@@ -506,6 +516,104 @@ def test_full_size_c4_two_kernels_agree(pkg):
         torch.cuda.synchronize()
         assert p.stats()["n_leftover"] == 0
         assert torch.equal(gi, idx[sel]) and torch.equal(gd, d2[sel])
+
+
+def test_full_size_c4_against_the_oracle_in_sub_boxes(pkg, oracle):
+    """BASELINE config 4 at full size against an answer that does not depend on the grid: the oracle streams the generator
+    over all 1e9 source indices on the host (never holding the cloud) and keeps the points inside 64 small boxes; the targets
+    inside the INNER part of each box are brute-forced against them.  Every such k-th distance is smaller than the margin
+    between inner and outer box, so no point outside the outer box can be (or tie with) a neighbour: the brute-force answer
+    IS the answer over the whole cloud, and the GPU rows must equal it bit for bit (indices, distances) -- a build that lost,
+    duplicated or misplaced records in these regions cannot pass.  Also: the fused blend of those rows within 1e-5."""
+    import torch
+    n, m, k, seed = 1_000_000_000, 50_000_000, 8, 0xC4
+    a, g = np.float32(0.008), np.float32(0.004)              # inner side, margin (k-th distance at this density: ~1.2e-3)
+    xs = np.array([0.0, 0.3137, 0.62, 1.0 - 0.008], np.float32)              # four x-slabs (both faces of the cube among them)
+    yz = np.array([0.0, 0.2501, 0.5003, 1.0 - 0.008], np.float32)
+    inner_lo = np.array([[x, y, z] for x in xs for y in yz for z in yz], np.float32)
+    inner_hi = inner_lo + a
+    outer_lo, outer_hi = inner_lo - g, inner_hi + g
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.build_synth(n, seed)
+        p.targets_synth(m, seed)
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        rgb = torch.empty((m, 3), dtype=torch.float32, device="cuda"); nrm = torch.empty((m, 3), dtype=torch.float32, device="cuda")
+        p.query_blend_resident_dev(k, pkg.BLEND_MEAN, idx, d2, rgb, nrm)
+        torch.cuda.synchronize()
+        sxyz, sidx, sbox = oracle.synth_filter_boxes(seed, 0, n, outer_lo, outer_hi)
+        txyz, tidx, tbox = oracle.synth_filter_boxes(seed, 1, m, inner_lo, inner_hi)
+        assert len(tidx) > 500 and len(sidx) > 64 * 1000
+        rows = torch.from_numpy(tidx.astype(np.int64)).cuda()
+        I = idx[rows].cpu().numpy().view(np.uint32); D = d2[rows].cpu().numpy()
+        C = rgb[rows].cpu().numpy(); N = nrm[rows].cpu().numpy()
+    checked = 0
+    for b in range(len(inner_lo)):
+        ss, tt = np.nonzero(sbox == b)[0], np.nonzero(tbox == b)[0]
+        if not len(tt):
+            continue
+        wi, wd = oracle.knn_bruteforce(sxyz[:, ss], txyz[:, tt], k, gidx=sidx[ss])
+        assert (wd[:, k - 1] < float(g) * float(g)).all()                   # the margin argument holds for every row
+        assert np.array_equal(I[tt], wi) and np.array_equal(D[tt], wd), "box %d" % b
+        checked += len(tt)
+    assert checked == len(tidx)
+    # fused blend of the checked rows: attributes are index-addressable too
+    flat = I.reshape(-1).astype(np.int64)
+    uniq, inv = np.unique(flat, return_inverse=True)
+    arg = np.empty((len(uniq), 3), np.uint8); anr = np.empty((len(uniq), 3), np.float32)
+    for j, u in enumerate(uniq):
+        arg[j] = oracle.synth_rgb(seed, 1, i0=int(u))[0]; anr[j] = oracle.synth_nrm(seed, 1, i0=int(u))[0]
+    rc, rn = oracle.blend(inv.reshape(I.shape).astype(np.uint32), D, arg, anr, mode=0)
+    assert np.abs(C - rc).max() / 255.0 <= TOL and np.abs(N - rn).max() <= TOL
+
+
+def test_even_chunk_scatter_variant_against_oracle(pkg, oracle):
+    """Pass 1 of the build switches to 1024-thread workgroups (8192-record tiles) once a cloud has an even number of tiles
+    per chunk -- from 33.5 M points up.  40 M points: the smallest oracle-checked cloud that takes that variant."""
+    n, m, k, seed = 40_000_000, 20_000, 8, 0x40
+    src = oracle.synth_xyz(seed, 0, n)
+    tgt = oracle.synth_xyz(seed, 1, m)
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.build(src)
+        idx, d2 = p.query(tgt, k)
+    wi, wd = oracle.KdTree(src).query(tgt, k)
+    assert np.array_equal(idx, wi) and np.array_equal(d2, wd)
+
+
+def test_nan_coordinates(pkg, pt, oracle):
+    """A NaN source coordinate is an argument error (the bounding-box reductions must not swallow it); a NaN TARGET coordinate
+    gives that row PT_NOIDX / +inf in every slot and leaves the other rows alone."""
+    rng = np.random.default_rng(11)
+    src = rng.random((3, 5000), dtype=np.float32)
+    bad = src.copy(); bad[1, 1234] = np.nan
+    with pytest.raises(pkg.PtError) as e:
+        pt.build(bad)
+    assert e.value.code == pkg.capi.ERR_ARG
+    big = rng.random((3, 9_000_000), dtype=np.float32)                      # sampled-bounding-box path: pass 1 verifies the box
+    big[2, 8_765_432] = np.nan
+    with pytest.raises(pkg.PtError) as e:
+        pt.build(big)
+    assert e.value.code == pkg.capi.ERR_ARG
+    pt.build(src)
+    tgt = rng.random((3, 300), dtype=np.float32)
+    tgt[0, 7] = np.nan; tgt[2, 200] = np.nan
+    idx, d2 = pt.query(tgt, 8)
+    wi, wd = oracle.knn_bruteforce(src, tgt, 8)
+    good = np.ones(300, bool); good[[7, 200]] = False
+    assert np.array_equal(idx[good], wi[good]) and np.array_equal(d2[good], wd[good])
+    assert (idx[~good] == pkg.NOIDX).all() and np.isinf(d2[~good]).all()
+
+
+def test_cell_side_beyond_fp32_range(pkg, oracle):
+    """Coordinates scaled by 1e20: the squared cell side leaves fp32's range, where the tile kernel's fp32 pruning would
+    skip neighbouring cells -- such clouds must be answered by the fp64-pruning group kernel, bit-exact as ever."""
+    rng = np.random.default_rng(12)
+    src = (rng.random((3, 20000)) * 1e20).astype(np.float32)
+    tgt = (rng.random((3, 500)) * 1e20).astype(np.float32)
+    with pkg.PointsTransfer(device=0) as p:
+        p.build(src)
+        idx, d2 = p.query(tgt, 8)
+    wi, wd = oracle.knn_bruteforce(src, tgt, 8)
+    assert np.array_equal(idx, wi) and np.array_equal(d2, wd)
 
 
 @pytest.mark.parametrize("k,mode,tile", [(8, 0, 1), (8, 1, 1), (16, 0, 1), (20, 1, 1), (32, 0, 1), (8, 1, 0)])
