@@ -23,6 +23,7 @@ SYMBOLS = [
     "pt_num_source", "pt_query_aos", "pt_query_soa", "pt_targets_synth", "pt_targets_soa", "pt_targets_aos", "pt_num_targets", "pt_query_resident", "pt_query_blend_resident",
     "pt_resident_target_ids", "pt_resident_target_xyz", "pt_blend", "pt_blend_dev", "pt_blend_weighted", "pt_blend_weighted_dev", "pt_pca_normals",
     "pt_pca_normals_dev", "pt_merge_candidates_dev", "pt_slab_need_dev", "pt_pack_requests_dev", "pt_query_bounded_dev",
+    "pt_bake_texture", "pt_texture_pad",
 ]
 
 
@@ -35,7 +36,7 @@ class Stats(C.Structure):
         ("grid_dim", C.c_int32 * 3), ("n_levels", C.c_int32),
         ("cell_size", C.c_double), ("n_cells", C.c_uint64), ("device_bytes", C.c_uint64),
         ("ms_kernel", C.c_double * 8), ("n_leftover", C.c_uint64), ("rho_occupied", C.c_double),
-        ("n_refine", C.c_int32), ("bbox_guess", C.c_int32),
+        ("n_refine", C.c_int32), ("bbox_guess", C.c_int32), ("ms_bake", C.c_double),
     ]
 
 
@@ -95,6 +96,8 @@ def lib():
         "pt_slab_need_dev": (i32, [p, p, i32, p, u64, i32, i32, p, i32, i32, p]),
         "pt_pack_requests_dev": (i32, [p, p, i32, p, u64, i32, i32, p, i32, i32, p, p, p]),
         "pt_query_bounded_dev": (i32, [p, p, i32, p, u64, i32, p, p]),
+        "pt_bake_texture": (i32, [p, p, u64, p, u64, p, i32, i32, i32, p]),
+        "pt_texture_pad": (i32, [p, p, i32, i32, p]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():

@@ -1001,4 +1001,81 @@ int pt_pack_requests_dev(pt_ctx* c, const void* tgt_xyz_dev, int xyz_type, const
   return PT_OK;
 }
 
+// ---- texture bake (pt_bake.hip) ------------------------------------------------------------------------------------
+int pt_bake_texture(pt_ctx* c, const pt_point* mesh_vertices, uint64_t nv, const int32_t* faces, uint64_t nf, const uint32_t* nbr_idx, int k,
+                    int resolution, int pad_ksize, uint8_t* bgra_out) {
+  if (!c) return PT_ERR_ARG;
+  if (c->src_type != PT_F32 && c->src_type != PT_F64) return fail(c, PT_ERR_STATE, "no source cloud resident (call a pt_build_* first)");
+  if (c->has_gidx) return fail(c, PT_ERR_UNSUPPORTED, "the texture bake needs the whole cloud resident (not a slab)");
+  if (!c->has_attr) return fail(c, PT_ERR_STATE, "no attribute table resident (the bake reads the source colours)");
+  if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k = %d out of range [1, %d]", k, PT_MAX_K);
+  if (resolution < 1 || resolution > 32768) return fail(c, PT_ERR_ARG, "resolution out of range [1, 32768]");
+  if (pad_ksize < 0 || (pad_ksize > 0 && !(pad_ksize & 1)) || pad_ksize > 255) return fail(c, PT_ERR_ARG, "pad_ksize must be 0 or an odd number <= 255");
+  if (!bgra_out || (nv && !mesh_vertices) || (nf && (!faces || !nbr_idx))) return fail(c, PT_ERR_ARG, "null argument");
+  if (nf >= (1ull << 24)) return fail(c, PT_ERR_ARG, "nf = %llu: the pixel key holds 24 bits of face index", (unsigned long long)nf);
+  { int r = check_n(c, nv, "nv"); if (r) return r; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t npix = (size_t)resolution * (size_t)resolution;
+  DevBuf keys, tex, tmp, out, dv, df, dn;
+  auto cleanup = [&]() { DevBuf* all[] = {&keys, &tex, &tmp, &out, &dv, &df, &dn}; for (DevBuf* b : all) release(c, *b); };
+  auto run = [&]() -> int {
+    RES(c, keys, npix * 8); RES(c, tex, npix * 4);
+    RES(c, dv, std::max<uint64_t>(nv, 1) * sizeof(pt_point)); RES(c, df, std::max<uint64_t>(nf, 1) * 12); RES(c, dn, std::max<uint64_t>(nv, 1) * (size_t)k * 4);
+    HIPCHK(c, hipMemsetAsync(keys.p, 0, npix * 8, c->stream));
+    { int r = copy_in(c, dv.p, mesh_vertices, nv * sizeof(pt_point), 0); if (r) return r; }
+    { int r = copy_in(c, df.p, faces, nf * 12, 0); if (r) return r; }
+    { int r = copy_in(c, dn.p, nbr_idx, nv * (size_t)k * 4, 0); if (r) return r; }
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (c->src_type == PT_F32) {
+      const float* x = (const float*)c->in_xyz.p;
+      pt_launch_bake_faces<float>(x, x + c->n, x + 2 * c->n, (const Attr*)c->attr.p, (uint32_t)c->n, dv.p, (uint32_t)nv, (const int32_t*)df.p, (uint32_t)nf,
+                                  (const uint32_t*)dn.p, k, resolution, (unsigned long long*)keys.p, c->stream);
+    } else {
+      const double* x = (const double*)c->in_xyz.p;
+      pt_launch_bake_faces<double>(x, x + c->n, x + 2 * c->n, (const Attr*)c->attr.p, (uint32_t)c->n, dv.p, (uint32_t)nv, (const int32_t*)df.p, (uint32_t)nf,
+                                   (const uint32_t*)dn.p, k, resolution, (unsigned long long*)keys.p, c->stream);
+    }
+    pt_launch_bake_resolve((const unsigned long long*)keys.p, (uint32_t*)tex.p, npix, c->stream);
+    const void* result = tex.p;
+    if (pad_ksize > 0) {
+      RES(c, tmp, npix * 4); RES(c, out, npix * 4);
+      pt_launch_dilate_pad((const uint32_t*)tex.p, (uint32_t*)tmp.p, (uint32_t*)out.p, resolution, pad_ksize, c->stream);
+      result = out.p;
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(bgra_out, result, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->st.ms_bake = ms;
+    return PT_OK;
+  };
+  const int r = run();
+  cleanup();
+  return r;
+}
+
+int pt_texture_pad(pt_ctx* c, const uint8_t* bgra_in, int resolution, int ksize, uint8_t* bgra_out) {
+  if (!c) return PT_ERR_ARG;
+  if (resolution < 1 || resolution > 32768) return fail(c, PT_ERR_ARG, "resolution out of range [1, 32768]");
+  if (ksize < 1 || !(ksize & 1) || ksize > 255) return fail(c, PT_ERR_ARG, "ksize must be an odd number in [1, 255]");
+  if (!bgra_in || !bgra_out) return fail(c, PT_ERR_ARG, "null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t npix = (size_t)resolution * (size_t)resolution;
+  DevBuf tex, tmp, out;
+  auto run = [&]() -> int {
+    RES(c, tex, npix * 4); RES(c, tmp, npix * 4); RES(c, out, npix * 4);
+    { int r = copy_in(c, tex.p, bgra_in, npix * 4, 0); if (r) return r; }
+    pt_launch_dilate_pad((const uint32_t*)tex.p, (uint32_t*)tmp.p, (uint32_t*)out.p, resolution, ksize, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(bgra_out, out.p, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+  };
+  const int r = run();
+  release(c, tex); release(c, tmp); release(c, out);
+  return r;
+}
+
 }  // extern "C"

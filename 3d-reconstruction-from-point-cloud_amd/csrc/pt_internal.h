@@ -99,3 +99,15 @@ void pt_launch_pca(const uint32_t* idx, uint32_t m, int k, const T* x, const T* 
 void pt_launch_pack_posattr(const float* x, const float* y, const float* z, const Attr* attr, uint32_t n, void* out, hipStream_t s);
 void pt_launch_pca_posattr(const uint32_t* idx, uint32_t m, int k, const void* posattr, uint32_t n, int has_attr, float* nrm_out, hipStream_t s);
 void pt_launch_iota(uint32_t* p, uint32_t n, hipStream_t s);
+
+// ---- pt_bake.hip ------------------------------------------------------------------------------
+// per-face texture bake (reference src/pointsTransfer.cpp:466-581, :66-107): every covered pixel of the R x R atlas does an
+// atomicMax on keys[] (zeroed by the caller) with {face * 256 + triangle + 1, BGRA}; resolve keeps the BGRA of the last triangle.
+// sx/sy/sz: planar source xyz by ORIGINAL index; verts_aos: the mesh's 80-byte reference records (device copy);
+// nbr: the mesh vertices' neighbour lists [nv][k] (original indices).
+template <class T>
+void pt_launch_bake_faces(const T* sx, const T* sy, const T* sz, const Attr* attr, uint32_t n, const void* verts_aos, uint32_t nv, const int32_t* faces,
+                          uint32_t nf, const uint32_t* nbr, int k, int R, unsigned long long* keys, hipStream_t s);
+void pt_launch_bake_resolve(const unsigned long long* keys, uint32_t* bgra, size_t npix, hipStream_t s);
+// edge padding (reference :593-611): out = tex + (dilate(tex, ksize x ksize) & ~alpha), saturating; tmp: R*R words of scratch
+void pt_launch_dilate_pad(const uint32_t* tex, uint32_t* tmp, uint32_t* out, int R, int ksize, hipStream_t s);

@@ -5,14 +5,17 @@
 // :178,255,261,314,315,456,587,590,616,619,622,623 the report lines).  What runs between the lines is
 // different: the kd-tree build (:259) and the per-corner K_neighbor_search loop (:462-479) are replaced by
 // pt_build_aos / pt_query_aos of libpt_hip.so, each mesh VERTEX is searched once (the reference searches
-// every face corner, i.e. every vertex ~6 times), and the neighbours' colour/normal are blended onto the
-// vertex.  The texture bake that consumes the neighbours in the reference (:484-615, CGAL Delaunay + OpenCV)
-// is outside this path: instead of texture.png the tool writes transfer.ply, the mesh
-// with the transferred per-vertex colour and normal.
+// every face corner, i.e. every vertex ~6 times), the per-face texture bake that consumes the neighbours
+// (:466-581 projection / in-triangle filter / Delaunay / draw_triangle, :593-611 dilate + edge padding; CGAL and
+// OpenCV in the reference) is pt_bake_texture of the same library, and the PNG (:613-615, cv::imwrite) is written by
+// host/png_write.h.  Output artefacts: texture.png in the working directory, as the reference, and -- the
+// per-vertex product of BASELINE.json's north_star -- transfer.ply, the mesh with the neighbours' blended colour / normal.
 //
-// Optional flags after the two positionals (the reference has none; K is its compile-time constant, :128):
+// Optional flags after the two positionals (the reference has none; K and RESOLUTION are its compile-time constants, :128-129):
 //   --k K            neighbours per vertex, default 20            --blend mean|invd2   default mean
-//   --out FILE       default transfer.ply                          --device D           default 0
+//   --out FILE       default transfer.ply ("" = do not write)      --device D           default 0
+//   --texture FILE   default texture.png ("" = no bake)            --resolution R       default 8192
+//   --pad K          edge-padding kernel, default 25 (0 = none)
 //   --neighbors FILE also dump the neighbour indices (binary u32[M][K])
 //   --ply-threads T  parser threads for the two input files (default 0 = one per hardware thread; host/ply_fast.h)
 // There is no CPU path: without a usable GPU the tool reports the error and exits non-zero.
@@ -29,6 +32,7 @@
 
 #include "Point.h"
 #include "ply_fast.h"
+#include "png_write.h"
 #include "pt_api.h"
 
 namespace {
@@ -56,8 +60,8 @@ int main(int argc, char** argv) {
     return 0;
   }
   const std::string pc_file_name = argv[1], mesh_file_name = argv[2];
-  int K = 20, device = 0, mode = PT_BLEND_MEAN, ply_threads = 0;
-  std::string out_name = "transfer.ply", nbr_name;
+  int K = 20, device = 0, mode = PT_BLEND_MEAN, ply_threads = 0, resolution = 8192, pad = 25;     // K, RESOLUTION: reference :128-129; 25: :594
+  std::string out_name = "transfer.ply", nbr_name, tex_name = "texture.png";                      // texture.png: reference :615
   for (int i = 3; i < argc; ++i) {
     const std::string a = argv[i];
     auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
@@ -65,11 +69,15 @@ int main(int argc, char** argv) {
     else if (a == "--device") device = std::atoi(val());
     else if (a == "--out") out_name = val();
     else if (a == "--neighbors") nbr_name = val();
+    else if (a == "--texture") tex_name = val();
+    else if (a == "--resolution") resolution = std::atoi(val());
+    else if (a == "--pad") pad = std::atoi(val());
     else if (a == "--ply-threads") ply_threads = std::max(0, std::atoi(val()));
     else if (a == "--blend") mode = std::string(val()) == "invd2" ? PT_BLEND_INV_D2 : PT_BLEND_MEAN;
     else { std::cerr << "unknown option " << a << std::endl; return 2; }
   }
   if (K < 1 || K > PT_MAX_K) { std::cerr << "--k must be in [1, " << PT_MAX_K << "]" << std::endl; return 2; }
+  if (resolution < 1 || resolution > 32768 || pad < 0 || pad > 255 || (pad > 0 && !(pad & 1))) { std::cerr << "--resolution must be in [1, 32768], --pad 0 or odd" << std::endl; return 2; }
 
   const auto t_total = clk::now();
   auto t_task = clk::now();
@@ -118,11 +126,26 @@ int main(int argc, char** argv) {
   rc = pt_blend(ctx, idx.data(), d2.data(), M, K, mode, rgb.data(), nrm.data());
   if (rc != PT_OK) { std::cerr << "pointsTransfer: blend failed: " << pt_last_error(ctx) << std::endl; pt_ctx_destroy(ctx); return 1; }
   const double t_blend = since(t_task);
-  std::cout << "Neighbor search total time: " << t_search << " seconds" << std::endl;
-  std::cout << "Draw triangles total time: " << t_blend << " seconds" << std::endl;   // here: attribute blend (no texture bake)
   t_task = clk::now();
+  // the reference's face loop after the search (:484-581) and its post-processing (:593-611), on the GPU
+  std::vector<uint8_t> texture;
+  if (!tex_name.empty()) {
+    texture.resize((size_t)resolution * (size_t)resolution * 4);
+    rc = pt_bake_texture(ctx, reinterpret_cast<const pt_point*>(mesh.vertices.data()), M, mesh.faces.data(), mesh.faces.size() / 3, idx.data(), K, resolution,
+                         pad, texture.data());
+    if (rc != PT_OK) { std::cerr << "pointsTransfer: texture bake failed: " << pt_last_error(ctx) << std::endl; pt_ctx_destroy(ctx); return 1; }
+  }
+  const double t_bake = since(t_task);
+  std::cout << "Neighbor search total time: " << t_search << " seconds" << std::endl;
+  std::cout << "Draw triangles total time: " << t_bake + t_blend << " seconds" << std::endl;   // texture bake (+ the per-vertex blend)
+  t_task = clk::now();
+  if (!tex_name.empty() && !png::write_bgra(tex_name, texture.data(), resolution, resolution)) {
+    std::cerr << "pointsTransfer: cannot write " << tex_name << std::endl;
+    pt_ctx_destroy(ctx);
+    return 1;
+  }
 
-  {   // output: the mesh with transferred colour/normal.  Formatted in parallel (one chunk of records per thread, "%.9g" =
+  if (!out_name.empty()) {   // output: the mesh with transferred colour/normal.  Formatted in parallel (one chunk of records per thread, "%.9g" =
       // what operator<< prints at precision 9), written in order.
     std::ofstream o(out_name, std::ios::binary);
     o << "ply\nformat ascii 1.0\nelement vertex " << M << "\n"
@@ -170,7 +193,7 @@ int main(int argc, char** argv) {
   pt_stats_t st;
   if (pt_stats(ctx, &st) == PT_OK)
     std::cerr << "[pt_hip] grid " << st.grid_dim[0] << "x" << st.grid_dim[1] << "x" << st.grid_dim[2] << " cells, build " << st.ms_build
-              << " ms, target sort " << st.ms_sort_targets << " ms, kNN " << st.ms_query << " ms, blend " << st.ms_blend << " ms (device time)"
+              << " ms, target sort " << st.ms_sort_targets << " ms, kNN " << st.ms_query << " ms, blend " << st.ms_blend << " ms, texture bake " << st.ms_bake << " ms (device time)"
               << std::endl;
   pt_ctx_destroy(ctx);
 

@@ -104,7 +104,9 @@ class GpuSlabEngine:
     def pack_requests(self, xyz, d2, k, axis, bounds, my_slab):
         """slab_need and the selection of the crossing targets fused on the device: (rows [c] int64, packets [c, 5] f64)."""
         m = xyz.shape[1]
-        if getattr(self, "_req_cap", 0) < m:                 # scratch sized for every target once, reused by later steps
+        if getattr(self, "_req_sel", None) is None or self._req_cap < m:   # scratch sized for every target once, reused by later
+            # steps -- allocated on the first call even when this rank holds NO targets (a mesh that covers only part of the
+            # slab axis): the empty views returned below must exist, or this rank dies before the collective the others wait in
             self._req_sel = torch.empty((m,), dtype=torch.int32, device=self.device)
             self._req_pkt = torch.empty((m, 5), dtype=torch.float64, device=self.device)
             self._req_cap = m

@@ -240,6 +240,26 @@ class PointsTransfer:
         self._adopt_torch_stream()
         self._chk(self._L.pt_pca_normals_dev(self._h, _ptr(idx_dev), m, k, _ptr(nrm_out_dev)))
 
+    # -- texture bake (pointsTransfer.cpp:466-615) ------------------------------------------------
+    def bake_texture(self, mesh_vertices, faces, nbr_idx, resolution=8192, pad_ksize=0):
+        """mesh_vertices: POINT_DTYPE records (ver, color, U, V are read); faces: int32 (F, 3); nbr_idx: uint32 (V, k) from a
+        query of those vertices.  Returns the (resolution, resolution, 4) BGRA atlas; pad_ksize > 0 applies the edge padding."""
+        v = np.ascontiguousarray(mesh_vertices)
+        assert v.dtype.itemsize == 80
+        f = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
+        nb = np.ascontiguousarray(nbr_idx, dtype=np.uint32)
+        assert nb.ndim == 2 and nb.shape[0] == v.shape[0]
+        out = np.empty((resolution, resolution, 4), np.uint8)
+        self._chk(self._L.pt_bake_texture(self._h, _ptr(v), v.shape[0], _ptr(f), f.shape[0], _ptr(nb), nb.shape[1], resolution, pad_ksize, _ptr(out)))
+        return out
+
+    def texture_pad(self, bgra, ksize=25):
+        a = np.ascontiguousarray(bgra, dtype=np.uint8)
+        assert a.ndim == 3 and a.shape[0] == a.shape[1] and a.shape[2] == 4
+        out = np.empty_like(a)
+        self._chk(self._L.pt_texture_pad(self._h, _ptr(a), a.shape[0], ksize, _ptr(out)))
+        return out
+
     # -- multi-GPU helpers (SURVEY.md 8e) ---------------------------------------------------------
     def merge_candidates_dev(self, idx_lists_dev, d2_lists_dev, g, m, k, idx_out_dev, d2_out_dev):
         self._adopt_torch_stream()

@@ -87,6 +87,7 @@ typedef struct pt_stats_t {
   int32_t n_refine;         /* how many times the last build refined its cell size */
   int32_t bbox_guess;       /* last build: 0 the bounding box came from a pass of its own; 1 the grid was laid out from a sampled
                              * box and pass 1 verified it (big clouds); -1 the sampled box was too small and the build was redone */
+  double ms_bake;           /* texture bake (+ edge padding) of the last pt_bake_texture, device time */
 } pt_stats_t;
 
 /* ---- context ------------------------------------------------------------------------ */
@@ -201,6 +202,23 @@ int  pt_pack_requests_dev(pt_ctx*, const void* tgt_xyz_dev, int xyz_type, const 
  * d2 <= bound2[t] are returned. */
 int  pt_query_bounded_dev(pt_ctx*, const void* xyz_dev, int xyz_type, const double* bound2_dev, uint64_t m,
                           int k, uint32_t* idx_dev, double* d2_dev);
+
+/* ---- texture bake: the consumer of the neighbour lists -------------------------------------
+ * pt_bake_texture replaces the body of the reference's face loop after the search and its rasteriser
+ * (src/pointsTransfer.cpp:466-581 and draw_triangle :66-107): per face, the union of its three corners' neighbour
+ * lists, projection into the face plane, the in-triangle filter, a Delaunay triangulation of corners + interior
+ * points, and barycentric rasterisation of every sub-triangle into a resolution x resolution BGRA atlas addressed
+ * (resolution - j, i) as the reference does.  pad_ksize > 0 additionally applies the reference's edge padding
+ * (:593-611: ksize x ksize dilate, ~alpha mask, saturating add; the reference uses 25) before the atlas is copied out.
+ * The source cloud must be resident (pt_build_*); `mesh_vertices` are the reference's records (ver, color, U, V are
+ * read), `faces` holds 3 vertex indices per face, `nbr_idx` is the [nv][k] index matrix a pt_query_* call returned
+ * for those vertices.  All host memory; bgra_out receives resolution * resolution * 4 bytes (B, G, R, A).
+ * Where the reference's result is decided by CGAL / OpenCV internals or by undefined behaviour the result is defined
+ * by this build (oracle/pt_oracle.c states the definition; INTEGRATION.md lists the points). */
+int  pt_bake_texture(pt_ctx*, const pt_point* mesh_vertices, uint64_t nv, const int32_t* faces, uint64_t nf,
+                     const uint32_t* nbr_idx, int k, int resolution, int pad_ksize, uint8_t* bgra_out);
+/* The edge padding alone (reference :593-611) on a host BGRA image. */
+int  pt_texture_pad(pt_ctx*, const uint8_t* bgra_in, int resolution, int ksize, uint8_t* bgra_out);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,8 @@ def lib():
         L.pto_blend.argtypes = [p, p, u64, i32, i32, p, p, p, p]
         L.pto_blend_weighted.argtypes = [p, p, u64, i32, p, p, p, p]
         L.pto_pca_normals.argtypes = [p, u64, i32, p, u64, p, p, p]
+        L.pto_bake_texture.argtypes = [p, p, u64, p, p, p, u64, p, u64, p, i32, i32, p]
+        L.pto_dilate_pad.argtypes = [p, i32, i32, p]
         _lib = L
     return _lib
 
@@ -233,6 +235,29 @@ def pca_normals(idx, src, nrm=None):
     out = np.zeros((m, 3), np.float32); plan = np.zeros(m)
     lib().pto_pca_normals(_ptr(idx), m, k, _ptr(src), src.shape[1], _ptr(nrm), _ptr(out), _ptr(plan))
     return out, plan
+
+
+def bake_texture(src_xyz, src_rgb, vert_xyz, vert_uv, vert_rgb, faces, nbr_idx, resolution):
+    """Per-face texture bake, the build's definition (pt_oracle.c: pto_bake_texture; reference pointsTransfer.cpp:462-581, :66-107).
+    src_xyz (3, n) / vert_xyz (3, nv) planar, *_rgb (., 3) uint8, vert_uv (nv, 2), faces (nf, 3) int32, nbr_idx (nv, k) uint32.
+    Returns the (R, R, 4) BGRA atlas."""
+    sx = _planar64(src_xyz); vx = _planar64(vert_xyz)
+    srgb = np.ascontiguousarray(src_rgb, np.uint8); vrgb = np.ascontiguousarray(vert_rgb, np.uint8)
+    uv = np.ascontiguousarray(vert_uv, np.float64); fc = np.ascontiguousarray(faces, np.int32).reshape(-1, 3)
+    nb = np.ascontiguousarray(nbr_idx, np.uint32)
+    out = np.zeros((resolution, resolution, 4), np.uint8)
+    rc = lib().pto_bake_texture(_ptr(sx), _ptr(srgb), sx.shape[1], _ptr(vx), _ptr(uv), _ptr(vrgb), vx.shape[1], _ptr(fc), fc.shape[0], _ptr(nb), nb.shape[1],
+                                resolution, _ptr(out))
+    assert rc == 0
+    return out
+
+
+def dilate_pad(bgra, ksize=25):
+    """Edge padding (pointsTransfer.cpp:593-611): texture + (dilate(texture, ksize x ksize) & ~alpha), saturating."""
+    a = np.ascontiguousarray(bgra, np.uint8)
+    out = np.empty_like(a)
+    assert lib().pto_dilate_pad(_ptr(a), a.shape[0], ksize, _ptr(out)) == 0
+    return out
 
 
 def ref_point_layout():

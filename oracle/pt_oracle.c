@@ -620,3 +620,201 @@ int pto_pca_normals(const uint32_t* idx, uint64_t m, int k, const double* src, u
   }
   return 0;
 }
+
+/* ========================================================================= */
+/* Per-face texture bake and edge padding (f3): CPU restatement  */
+/* of reference src/pointsTransfer.cpp:462-581 (face loop), :66-107              */
+/* (draw_triangle) and :593-615 (dilate / alpha mask / add).                      */
+/*                                                                               */
+/* PARITY: unpinned.  The reference delegates the plane frame (Plane_3::to_2d),   */
+/* the barycentric coordinates and the per-face Delaunay triangulation to CGAL   */
+/* and the dilation to OpenCV; neither library is in this image and the           */
+/* reference holds no fixture for them.  What the reference's own lines fix is     */
+/* restated literally (the data flow, the inside test bc >= 0, the UV              */
+/* interpolation :569-574, the rasteriser's pixel loop, colour mix and            */
+/* (resolution - j, i) addressing :68-103, the 25x25 dilate + ~alpha mask + add    */
+/* :593-611); where it leans on library behaviour or on undefined behaviour the    */
+/* BUILD defines the result, and this file is that definition:                     */
+/*  - the 3 corners' neighbour lists are united and de-duplicated by ORIGINAL       */
+/*    INDEX, ascending (the reference's std::set with a non-strict-weak            */
+/*    comparator, Point.h:94-102, dedupes only partially and is not reproducible);  */
+/*  - plane frame: orthonormal (e1 along corner0->corner1, e2 = n x e1), origin at  */
+/*    corner 0; any affine frame gives the same barycentrics, and an orthonormal    */
+/*    one makes the Delaunay triangulation the true in-plane one;                    */
+/*  - a neighbour whose 2-D image coincides with an earlier point's is dropped;      */
+/*  - Delaunay = every non-degenerate triple (i<j<k) whose circumcircle holds no     */
+/*    other point strictly inside, predicates in plain fp64 evaluated on the          */
+/*    index-SORTED tuple with the permutation's sign applied (so the two diagonals    */
+/*    of a quad never both fail); co-circular points yield overlapping triangles,      */
+/*    which is harmless because of the next rule;                                    */
+/*  - a pixel covered by several triangles takes the LAST one in (face, triangle)     */
+/*    order -- what the reference's single-threaded loop produces;                   */
+/*  - writes outside the texture (row resolution - j for j = 0, negative indices;     */
+/*    undefined behaviour in the reference) are skipped; the texture starts as zeros   */
+/*    (the reference's cv::Mat is uninitialised); colours are clamped to 0..255.       */
+/* All arithmetic fp64, every operation individually rounded (-ffp-contract=off).  */
+/* ========================================================================= */
+typedef struct { double x, y; } v2;
+static inline double cross2(double ax, double ay, double bx, double by) { return ax * by - ay * bx; }
+/* barycentric coordinates of X in (v0,v1,v2), A = cross(v1-v0, v2-v0) != 0 */
+static inline void bary2(v2 X, v2 v0, v2 v1, v2 v2_, double A, double* b) {
+  b[0] = cross2(v1.x - X.x, v1.y - X.y, v2_.x - X.x, v2_.y - X.y) / A;
+  b[1] = cross2(v2_.x - X.x, v2_.y - X.y, v0.x - X.x, v0.y - X.y) / A;
+  b[2] = (1.0 - b[0]) - b[1];
+}
+static inline int finite_d(double v) { return v == v && v - v == 0.0; }
+/* reference draw_triangle (:66-107) on a zero-initialised BGRA image; see the rules above */
+static void pto_draw_triangle(const double* U, const double* V, const uint8_t (*col)[3], int R, uint8_t* bgra) {
+  v2 p = {U[0] * R, V[0] * R}, q = {U[1] * R, V[1] * R}, r = {U[2] * R, V[2] * R};
+  if (!(finite_d(p.x) && finite_d(p.y) && finite_d(q.x) && finite_d(q.y) && finite_d(r.x) && finite_d(r.y))) return;
+  const double A = cross2(q.x - p.x, q.y - p.y, r.x - p.x, r.y - p.y);
+  if (!(A != 0.0) || !finite_d(A)) return;
+  double xmin = fmin(p.x, fmin(q.x, r.x)), xmax = fmax(p.x, fmax(q.x, r.x));
+  double ymin = fmin(p.y, fmin(q.y, r.y)), ymax = fmax(p.y, fmax(q.y, r.y));
+  double fi0 = floor(xmin), fi1 = floor(xmax), fj0 = floor(ymin), fj1 = floor(ymax);
+  /* only pixels that land inside the texture: col i in [0, R), row R - j in [0, R) <=> j in [1, R] */
+  const int i0 = (int)fmax(fi0, 0.0), i1 = (int)fmin(fi1, (double)(R - 1));
+  const int j0 = (int)fmax(fj0, 1.0), j1 = (int)fmin(fj1, (double)R);
+  for (int i = i0; i <= i1; ++i)
+    for (int j = j0; j <= j1; ++j) {
+      const int x = i >= R ? R - 1 : i, y = j >= R ? R - 1 : j;          /* :80-82 */
+      v2 X = {(double)x, (double)y};
+      double b[3];
+      bary2(X, p, q, r, A, b);
+      if (b[0] >= 0 && b[1] >= 0 && b[2] >= 0) {
+        uint8_t* px = bgra + ((size_t)(R - j) * (size_t)R + (size_t)i) * 4;
+        for (int c = 0; c < 3; ++c) {                                     /* :95-97: double products, summed, stored to a float */
+          const float f = (float)((b[0] * (double)col[0][c] + b[1] * (double)col[1][c]) + b[2] * (double)col[2][c]);
+          const float g = f < 0.f ? 0.f : (f > 255.f ? 255.f : f);
+          px[2 - c] = (uint8_t)g;                                         /* B, G, R <- colour b, g, r (:100-102), truncated */
+        }
+        px[3] = 255;
+      }
+    }
+}
+#define PTO_BAKE_MAXPTS 99            /* 3 corners + 3 * 32 neighbours */
+static int cmp_u32(const void* a, const void* b) { const uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b; return x < y ? -1 : (x > y); }
+/* lifted 4-point determinant on the index-sorted tuple (w<x<y<z): > 0 iff z is inside the circle through w, x, y when those are
+ * counter-clockwise */
+static inline double incircle_sorted(const v2* P, int w, int x, int y, int z) {
+  const double adx = P[w].x - P[z].x, ady = P[w].y - P[z].y, bdx = P[x].x - P[z].x, bdy = P[x].y - P[z].y, cdx = P[y].x - P[z].x, cdy = P[y].y - P[z].y;
+  const double al = adx * adx + ady * ady, bl = bdx * bdx + bdy * bdy, cl = cdx * cdx + cdy * cdy;
+  return (al * (bdx * cdy - bdy * cdx) - bl * (adx * cdy - ady * cdx)) + cl * (adx * bdy - ady * bdx);
+}
+/* is point l strictly inside the circumcircle of the triangle (i<j<k) whose orientation sign is `os` (+1 ccw, -1 cw)? */
+static inline int in_circumcircle(const v2* P, int i, int j, int k, int l, int os) {
+  double d; int par;
+  if (l > k) { d = incircle_sorted(P, i, j, k, l); par = 1; }
+  else if (l > j) { d = incircle_sorted(P, i, j, l, k); par = -1; }
+  else if (l > i) { d = incircle_sorted(P, i, l, j, k); par = 1; }
+  else { d = incircle_sorted(P, l, i, j, k); par = -1; }
+  return (double)(os * par) * d > 0.0;
+}
+int pto_bake_texture(const double* src_xyz, const uint8_t* src_rgb, uint64_t n, const double* vert_xyz, const double* vert_uv,
+                     const uint8_t* vert_rgb, uint64_t nv, const int32_t* faces, uint64_t nf, const uint32_t* nbr_idx, int k,
+                     int R, uint8_t* bgra) {
+  if (k < 1 || k > 32 || R < 1) return -1;
+  for (uint64_t f = 0; f < nf; ++f) {
+    const int32_t* fv = faces + 3 * f;
+    if (fv[0] < 0 || fv[1] < 0 || fv[2] < 0 || (uint64_t)fv[0] >= nv || (uint64_t)fv[1] >= nv || (uint64_t)fv[2] >= nv) continue;   /* malformed face: skipped */
+    double cu[3], cv[3], c3[3][3];
+    uint8_t ccol[3][3];
+    for (int c = 0; c < 3; ++c) {
+      cu[c] = vert_uv[2 * (size_t)fv[c]]; cv[c] = vert_uv[2 * (size_t)fv[c] + 1];
+      for (int a = 0; a < 3; ++a) { c3[c][a] = vert_xyz[(size_t)a * nv + (size_t)fv[c]]; ccol[c][a] = vert_rgb[3 * (size_t)fv[c] + a]; }
+    }
+    /* union of the three corners' neighbour lists by original index, ascending (:470-479) */
+    uint32_t ids[96]; int nid = 0;
+    for (int c = 0; c < 3; ++c)
+      for (int j = 0; j < k; ++j) { const uint32_t id = nbr_idx[(size_t)fv[c] * k + j]; if (id != PTO_NOIDX && id < n) ids[nid++] = id; }
+    qsort(ids, (size_t)nid, sizeof(uint32_t), cmp_u32);
+    { int w = 0; for (int j = 0; j < nid; ++j) if (j == 0 || ids[j] != ids[j - 1]) ids[w++] = ids[j]; nid = w; }
+    /* plane frame (:485-494): origin corner 0, e1 along corner0 -> corner1, e2 = n x e1, both unit */
+    const double ax = c3[1][0] - c3[0][0], ay = c3[1][1] - c3[0][1], az = c3[1][2] - c3[0][2];
+    const double bx = c3[2][0] - c3[0][0], by = c3[2][1] - c3[0][1], bz = c3[2][2] - c3[0][2];
+    const double nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    const double la = sqrt((ax * ax + ay * ay) + az * az);
+    const double e1x = ax / la, e1y = ay / la, e1z = az / la;
+    const double tx = ny * e1z - nz * e1y, ty = nz * e1x - nx * e1z, tz = nx * e1y - ny * e1x;
+    const double lt = sqrt((tx * tx + ty * ty) + tz * tz);
+    const double e2x = tx / lt, e2y = ty / lt, e2z = tz / lt;
+    v2 P[PTO_BAKE_MAXPTS];
+    double PU[PTO_BAKE_MAXPTS], PV[PTO_BAKE_MAXPTS];
+    uint8_t PC[PTO_BAKE_MAXPTS][3];
+    int np = 3;
+    const int frame_ok = la > 0.0 && lt > 0.0 && finite_d(la) && finite_d(lt);
+    P[0].x = 0.0; P[0].y = 0.0;
+    P[1].x = (ax * e1x + ay * e1y) + az * e1z; P[1].y = (ax * e2x + ay * e2y) + az * e2z;
+    P[2].x = (bx * e1x + by * e1y) + bz * e1z; P[2].y = (bx * e2x + by * e2y) + bz * e2z;
+    for (int c = 0; c < 3; ++c) { PU[c] = cu[c]; PV[c] = cv[c]; memcpy(PC[c], ccol[c], 3); }
+    const double A = frame_ok ? cross2(P[1].x - P[0].x, P[1].y - P[0].y, P[2].x - P[0].x, P[2].y - P[0].y) : 0.0;
+    if (frame_ok && A != 0.0 && finite_d(A)) {
+      for (int j = 0; j < nid; ++j) {                                   /* :505-537: project, barycentrics, keep what is inside */
+        const size_t id = ids[j];
+        const double dx = src_xyz[id] - c3[0][0], dy = src_xyz[n + id] - c3[0][1], dz = src_xyz[2 * n + id] - c3[0][2];
+        v2 X = {(dx * e1x + dy * e1y) + dz * e1z, (dx * e2x + dy * e2y) + dz * e2z};
+        double b[3];
+        bary2(X, P[0], P[1], P[2], A, b);
+        if (!(b[0] >= 0 && b[1] >= 0 && b[2] >= 0)) continue;
+        int dup = 0;
+        for (int q = 0; q < np; ++q) dup |= (P[q].x == X.x && P[q].y == X.y);
+        if (dup) continue;
+        P[np] = X;
+        PU[np] = (b[0] * cu[0] + b[1] * cu[1]) + b[2] * cu[2];          /* :571-572 */
+        PV[np] = (b[0] * cv[0] + b[1] * cv[1]) + b[2] * cv[2];
+        PC[np][0] = src_rgb[3 * id]; PC[np][1] = src_rgb[3 * id + 1]; PC[np][2] = src_rgb[3 * id + 2];
+        ++np;
+      }
+    }
+    if (np == 3) {                                                       /* :540-544 */
+      pto_draw_triangle(PU, PV, (const uint8_t(*)[3])PC, R, bgra);
+      continue;
+    }
+    int ntri = 0;                                                        /* at most 255 triangles per face (2 np - 5 <= 193 unless many points are co-circular) */
+    for (int i = 0; i < np - 2; ++i)                                     /* :546-581 with the build's Delaunay definition */
+      for (int j = i + 1; j < np - 1; ++j)
+        for (int kk = j + 1; kk < np; ++kk) {
+          const double o = cross2(P[j].x - P[i].x, P[j].y - P[i].y, P[kk].x - P[i].x, P[kk].y - P[i].y);
+          if (!(o != 0.0)) continue;
+          const int os = o > 0.0 ? 1 : -1;
+          int empty = 1;
+          for (int l = 0; l < np && empty; ++l) if (l != i && l != j && l != kk && in_circumcircle(P, i, j, kk, l, os)) empty = 0;
+          if (!empty || ntri >= 255) continue;
+          ++ntri;
+          const double tu[3] = {PU[i], PU[j], PU[kk]}, tv[3] = {PV[i], PV[j], PV[kk]};
+          uint8_t tc[3][3];
+          memcpy(tc[0], PC[i], 3); memcpy(tc[1], PC[j], 3); memcpy(tc[2], PC[kk], 3);
+          pto_draw_triangle(tu, tv, (const uint8_t(*)[3])tc, R, bgra);
+        }
+  }
+  return 0;
+}
+/* reference :593-611: dilate(texture, 25x25 rect), edges = dilated & ~alpha (all four channels), padded = texture + edges
+ * (saturating).  OpenCV's dilate ignores what lies outside the image (border value = the channel minimum). */
+int pto_dilate_pad(const uint8_t* in, int R, int ksize, uint8_t* out) {
+  if (ksize < 1 || !(ksize & 1)) return -1;
+  const int h = ksize / 2;
+  uint8_t* tmp = (uint8_t*)malloc((size_t)R * R * 4);
+  if (!tmp) return -1;
+#pragma omp parallel for
+  for (int y = 0; y < R; ++y)
+    for (int x = 0; x < R; ++x)
+      for (int c = 0; c < 4; ++c) {
+        uint8_t m = 0;
+        for (int d = -h; d <= h; ++d) { const int xx = x + d; if (xx >= 0 && xx < R) { const uint8_t v = in[((size_t)y * R + xx) * 4 + c]; if (v > m) m = v; } }
+        tmp[((size_t)y * R + x) * 4 + c] = m;
+      }
+#pragma omp parallel for
+  for (int y = 0; y < R; ++y)
+    for (int x = 0; x < R; ++x) {
+      const uint8_t mask = (uint8_t)~in[((size_t)y * R + x) * 4 + 3];
+      for (int c = 0; c < 4; ++c) {
+        uint8_t m = 0;
+        for (int d = -h; d <= h; ++d) { const int yy = y + d; if (yy >= 0 && yy < R) { const uint8_t v = tmp[((size_t)yy * R + x) * 4 + c]; if (v > m) m = v; } }
+        const int s = (int)in[((size_t)y * R + x) * 4 + c] + (int)(m & mask);
+        out[((size_t)y * R + x) * 4 + c] = (uint8_t)(s > 255 ? 255 : s);
+      }
+    }
+  free(tmp);
+  return 0;
+}

@@ -122,3 +122,39 @@ def test_metric_has_no_fma_in_query_kernels():
     # no scratch spills in the hot kernels
     priv = re.findall(r"\.private_segment_fixed_size:\s*(\d+)", s)
     assert priv and all(int(p) == 0 for p in priv)
+
+
+def test_png_writer_roundtrip(tmp_path):
+    """host/png_write.h (what writes texture.png in place of cv::imwrite, reference src/pointsTransfer.cpp:613-615): files written
+    with 1, 3 and 16 deflate threads decode -- CRCs, Adler-32 of the concatenated bands and all -- to the same pixels."""
+    import struct, subprocess, zlib
+    import numpy as np
+    subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "host"), "../png_selftest"])
+    w, h = 301, 1000
+    want = np.empty(w * h * 4, np.uint8)
+    s = 12345
+    i = np.arange(w * h * 4, dtype=np.uint64)
+    lcg = np.empty(w * h * 4, np.uint32)
+    for j in range(w * h * 4):                      # (the same LCG as the C++ side)
+        s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+        lcg[j] = s
+    noisy = ((i // 4 // w) % 7) == 0
+    want = np.where(noisy, (lcg >> 24).astype(np.uint8), ((i * 31) >> 3).astype(np.uint8)).reshape(h, w, 4)
+    for threads in (1, 3, 16):
+        out = tmp_path / ("t%d.png" % threads)
+        subprocess.check_call([os.path.join(PKG, "png_selftest"), str(out), str(w), str(h), str(threads)])
+        data = open(out, "rb").read()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        off, idat = 8, []
+        while off < len(data):
+            ln, typ = struct.unpack(">I4s", data[off:off + 8])
+            body = data[off + 8:off + 8 + ln]
+            assert struct.unpack(">I", data[off + 8 + ln:off + 12 + ln])[0] == (zlib.crc32(typ + body) & 0xFFFFFFFF)
+            if typ == b"IHDR":
+                assert struct.unpack(">IIBBBBB", body) == (w, h, 8, 6, 0, 0, 0)
+            if typ == b"IDAT":
+                idat.append(body)
+            off += 12 + ln
+        raw = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8).reshape(h, w * 4 + 1)
+        assert (raw[:, 0] == 0).all()
+        assert np.array_equal(raw[:, 1:].reshape(h, w, 4)[:, :, [2, 1, 0, 3]], want)

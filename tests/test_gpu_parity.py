@@ -252,8 +252,10 @@ def test_cli_end_to_end(tmp_path, pkg, oracle):
         f.write("3 0 1 2\n3 2 1 3\n")
     exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "pointsTransfer")
     nb = tmp_path / "nn.bin"
-    r = subprocess.run([exe, str(pc), str(mesh), "--neighbors", str(nb), "--out", str(tmp_path / "out.ply")], capture_output=True, text=True, cwd=tmp_path)
+    r = subprocess.run([exe, str(pc), str(mesh), "--neighbors", str(nb), "--out", str(tmp_path / "out.ply"), "--resolution", "256"],
+                       capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 0, r.stderr
+    assert os.path.getsize(tmp_path / "texture.png") > 100                 # the reference's artefact, in the working directory (:615)
     lines = [l.split(":")[0] for l in r.stdout.strip().splitlines()]
     assert lines == ["PC Point count", "Read point set in", "Built Kd tree in", "Mesh vertex count", "Mesh face count", "Read mesh faces",
                      "Neighbor search total time", "Draw triangles total time", "Output time", "Total real time", "VIRT", "RES"]   # reference order
@@ -566,6 +568,23 @@ def test_full_size_c4_against_the_oracle_in_sub_boxes(pkg, oracle):
     assert np.abs(C - rc).max() / 255.0 <= TOL and np.abs(N - rn).max() <= TOL
 
 
+def test_slab_engine_with_no_local_targets(pkg, oracle):
+    """A rank whose slab holds no targets still takes part in the exchange: its request packing returns empty tensors
+    (it used to raise before reaching the collective, leaving the other ranks blocked)."""
+    import torch
+    from pt_amd import sharding
+    src = oracle.synth_xyz(3, 0, 4000)
+    with pkg.PointsTransfer(device=0) as p:
+        p.build(src)
+        eng = sharding.GpuSlabEngine(p, pkg.F32, torch.device("cuda", 0))
+        xyz = torch.empty((3, 0), dtype=torch.float32, device="cuda"); d2 = torch.empty((0, 8), dtype=torch.float64, device="cuda")
+        sel, pkt = eng.pack_requests(xyz, d2, 8, 0, sharding.uniform_slab_bounds(2), 0)
+        assert sel.numel() == 0 and tuple(pkt.shape) == (0, 5)
+        idx = torch.empty((0, 8), dtype=torch.int32, device="cuda")
+        st = sharding.exchange_and_merge(sharding.SingleComm(), eng, xyz, idx, d2, 8, 0, sharding.uniform_slab_bounds(1))
+        assert st["crossing"] == 0
+
+
 def test_even_chunk_scatter_variant_against_oracle(pkg, oracle):
     """Pass 1 of the build switches to 1024-thread workgroups (8192-record tiles) once a cloud has an even number of tiles
     per chunk -- from 33.5 M points up.  40 M points: the smallest oracle-checked cloud that takes that variant."""
@@ -749,3 +768,105 @@ def test_double_cloud_with_coordinates_beyond_float_range(pkg, oracle):
         p.build(src, xyz_type=pkg.F64)
         got = p.query(tgt, 8, xyz_type=pkg.F64)
     _check_exact(got, oracle.knn_bruteforce(src, tgt, 8), "huge coordinates")
+
+
+# ---- texture bake: atlas bytes against the oracle ----------------------------------------------------
+@pytest.mark.parametrize("seed,n,grid,k,R,degenerate,f64", [(1, 6000, 6, 20, 512, False, True), (2, 20000, 9, 20, 700, False, False),
+                                                           (5, 3000, 3, 8, 128, True, True), (7, 1500, 2, 32, 257, True, False)])
+def test_texture_bake_matches_oracle(pkg, oracle, seed, n, grid, k, R, degenerate, f64):
+    from _bake_cases import make_case, point_records
+    src, rgb, verts, uv, vrgb, faces = make_case(seed, n=n, grid=grid, degenerate=degenerate)
+    if not f64:
+        src = src.astype(np.float32).astype(np.float64); verts = verts.astype(np.float32).astype(np.float64)
+    if degenerate:
+        uv = uv * 1.3 - 0.15
+        faces = np.vstack([faces, [[0, 1, 99999]]]).astype(np.int32)
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        if f64:
+            p.build_aos(point_records(pkg.POINT_DTYPE, src, rgb))
+            vrec = point_records(pkg.POINT_DTYPE, verts, vrgb, uv)
+            idx, d2 = p.query_aos(vrec, k)
+        else:
+            p.build(src.astype(np.float32), rgb, np.zeros((n, 3), np.float32))
+            vrec = point_records(pkg.POINT_DTYPE, verts, vrgb, uv)
+            idx, d2 = p.query(verts.astype(np.float32), k)
+        wi, wd = oracle.knn_bruteforce(src, verts, k)
+        assert np.array_equal(idx, wi)
+        if degenerate:
+            idx = idx.copy(); idx[3, :5] = 0xFFFFFFFF
+        got = p.bake_texture(vrec, faces, idx, R)
+        want = oracle.bake_texture(src, rgb, verts, uv, vrgb, faces, idx, R)
+        assert (want[:, :, 3] == 255).mean() > 0.3
+        assert np.array_equal(got, want)
+        # edge padding: alone, and fused into the bake call
+        wpad = oracle.dilate_pad(want, 25)
+        assert np.array_equal(p.texture_pad(got, 25), wpad)
+        assert np.array_equal(p.bake_texture(vrec, faces, idx, R, pad_ksize=25), wpad)
+        assert p.stats()["ms_bake"] > 0
+
+
+def test_texture_pad_matches_oracle_on_noise(pkg, oracle):
+    rng = np.random.default_rng(8)
+    R = 333
+    tex = np.zeros((R, R, 4), np.uint8)
+    m = rng.random((R, R)) < 0.05
+    tex[m] = rng.integers(0, 256, size=(int(m.sum()), 4), dtype=np.uint8)
+    with pkg.PointsTransfer(device=0) as p:
+        for ks in (1, 5, 25):
+            assert np.array_equal(p.texture_pad(tex, ks), oracle.dilate_pad(tex, ks))
+        with pytest.raises(pkg.PtError):
+            p.texture_pad(tex, 4)
+
+
+def _read_png_rgba(path):
+    """minimal PNG reader for the files host/png_write.h produces (8-bit RGBA, filter type 0 on every row)"""
+    import struct, zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    off, idat, w, h = 8, [], 0, 0
+    while off < len(data):
+        ln, typ = struct.unpack(">I4s", data[off:off + 8])
+        body = data[off + 8:off + 8 + ln]
+        assert struct.unpack(">I", data[off + 8 + ln:off + 12 + ln])[0] == (zlib.crc32(typ + body) & 0xFFFFFFFF), "chunk CRC"
+        if typ == b"IHDR":
+            w, h, depth, ctype, comp, flt, inter = struct.unpack(">IIBBBBB", body)
+            assert (depth, ctype, comp, flt, inter) == (8, 6, 0, 0, 0)
+        elif typ == b"IDAT":
+            idat.append(body)
+        off += 12 + ln
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8).reshape(h, w * 4 + 1)      # (checks the Adler-32 of the whole stream)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 4)
+
+
+def test_cli_writes_the_texture(tmp_path, pkg, oracle):
+    """pointsTransfer cloud.ply mesh.ply -> texture.png (reference src/pointsTransfer.cpp:613-615): search (K = 20), per-face bake,
+    25 x 25 edge padding and PNG writing, end to end through the C++ host, decoded and compared with the oracle's atlas."""
+    import os, subprocess
+    from _bake_cases import make_case
+    src, rgb, verts, uv, vrgb, faces = make_case(9, n=8000, grid=5)
+    n, m = src.shape[1], verts.shape[1]
+    pc, mesh = tmp_path / "cloud.ply", tmp_path / "mesh.ply"
+    with open(pc, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\n"
+                "property float ny\nproperty float nz\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % n)
+        for i in range(n):
+            f.write("%.17g %.17g %.17g 0 0 1 %d %d %d\n" % (*src[:, i], *rgb[i]))
+    with open(mesh, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\n"
+                "property float ny\nproperty float nz\nproperty float s\nproperty float t\nproperty uchar red\nproperty uchar green\n"
+                "property uchar blue\nelement face %d\nproperty list uchar int vertex_indices\nend_header\n" % (m, len(faces)))
+        for i in range(m):
+            f.write("%.17g %.17g %.17g 0 0 1 %.17g %.17g %d %d %d\n" % (*verts[:, i], *uv[i], *vrgb[i]))
+        for fc in faces:
+            f.write("3 %d %d %d\n" % tuple(fc))
+    exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "pointsTransfer")
+    R = 640
+    r = subprocess.run([exe, str(pc), str(mesh), "--resolution", str(R), "--out", ""], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert not os.path.exists(tmp_path / "transfer.ply")
+    got = _read_png_rgba(tmp_path / "texture.png")
+    idx, _ = oracle.knn_bruteforce(src, verts, 20)
+    want = oracle.dilate_pad(oracle.bake_texture(src, rgb, verts, uv, vrgb, faces, idx, R), 25)
+    assert got.shape == (R, R, 4)
+    assert np.array_equal(got[:, :, [2, 1, 0, 3]], want)                  # the file holds R, G, B, A; the atlas is B, G, R, A
