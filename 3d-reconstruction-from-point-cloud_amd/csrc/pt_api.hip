@@ -63,6 +63,10 @@ struct pt_ctx {
   DevBuf t_xyz, t_gidx, trec, trec_tmp;
   DevBuf x_xyz;                // transient targets of pt_query_soa / _aos / _bounded_dev (resident targets stay untouched)
   bool t_has_gidx = false;
+  // streamed upload (pt_upload_*)
+  uint64_t up_n = 0;
+  int up_type = -1, up_attr = 0;
+  DevBuf up_rgb, up_nrm;
   SortTables ttb{};
   DevBuf ttb_mem;
 
@@ -540,7 +544,7 @@ void pt_ctx_destroy(pt_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in_xyz, &c->in_gidx, &c->attr, &c->rec, &c->rec_tmp, &c->cell_start, &c->stb_mem, &c->t_xyz, &c->t_gidx, &c->trec,
-                   &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr, &c->retry, &c->rec32};
+                   &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr, &c->retry, &c->rec32, &c->up_rgb, &c->up_nrm};
   for (DevBuf* b : all) release(c, *b);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);
@@ -999,6 +1003,63 @@ int pt_pack_requests_dev(pt_ctx* c, const void* tgt_xyz_dev, int xyz_type, const
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *count_out = c->h_counter[6];
   return PT_OK;
+}
+
+// ---- streamed upload -----------------------------------------------------------------------------------------------
+void* pt_host_alloc(uint64_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void pt_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int pt_upload_begin(pt_ctx* c, uint64_t n, int xyz_type, int with_attributes) {
+  if (!c) return PT_ERR_ARG;
+  if (xyz_type != PT_F32 && xyz_type != PT_F64) return fail(c, PT_ERR_ARG, "pt_upload_begin: xyz_type must be PT_F32 or PT_F64");
+  { int r = check_n(c, n, "n"); if (r) return r; }
+  HIPCHK(c, hipSetDevice(c->device));
+  RES(c, c->in_xyz, std::max<uint64_t>(n, 1) * 3 * tsize(xyz_type));
+  if (with_attributes) {
+    RES(c, c->up_rgb, std::max<uint64_t>(n, 1) * 3);
+    RES(c, c->up_nrm, std::max<uint64_t>(n, 1) * 12);
+    RES(c, c->attr, std::max<uint64_t>(n, 1) * sizeof(Attr));
+  }
+  c->up_n = n; c->up_type = xyz_type; c->up_attr = with_attributes ? 1 : 0;
+  c->built = false; c->src_type = -1;            // nothing usable until pt_upload_end
+  return PT_OK;
+}
+
+int pt_upload_range(pt_ctx* c, uint64_t first, uint64_t count, const void* x, const void* y, const void* z, const uint8_t* rgb, const float* nrm) {
+  if (!c) return PT_ERR_ARG;
+  if (c->up_type < 0) return PT_ERR_STATE;                                    // (no error text: several threads may be in here)
+  if (first > c->up_n || count > c->up_n - first) return PT_ERR_ARG;
+  if (count && (!x || !y || !z || (c->up_attr && (!rgb || !nrm)))) return PT_ERR_ARG;
+  if (!count) return PT_OK;
+  if (hipSetDevice(c->device) != hipSuccess) return PT_ERR_HIP;               // the calling thread's current device
+  const size_t ts = tsize(c->up_type);
+  char* base = (char*)c->in_xyz.p;
+  const void* src[3] = {x, y, z};
+  for (int a = 0; a < 3; ++a)
+    if (hipMemcpyAsync(base + ((size_t)a * c->up_n + first) * ts, src[a], count * ts, hipMemcpyHostToDevice, c->stream) != hipSuccess) return PT_ERR_HIP;
+  if (c->up_attr) {
+    if (hipMemcpyAsync((char*)c->up_rgb.p + first * 3, rgb, count * 3, hipMemcpyHostToDevice, c->stream) != hipSuccess) return PT_ERR_HIP;
+    if (hipMemcpyAsync((char*)c->up_nrm.p + first * 12, nrm, count * 12, hipMemcpyHostToDevice, c->stream) != hipSuccess) return PT_ERR_HIP;
+  }
+  return PT_OK;
+}
+
+int pt_upload_end(pt_ctx* c) {
+  if (!c) return PT_ERR_ARG;
+  if (c->up_type < 0) return fail(c, PT_ERR_STATE, "pt_upload_end without pt_upload_begin");
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t n = c->up_n;
+  if (c->up_attr) pt_launch_pack_attr((const uint8_t*)c->up_rgb.p, (const float*)c->up_nrm.p, (uint32_t)n, (Attr*)c->attr.p, c->stream);
+  HIPCHK(c, hipStreamSynchronize(c->stream));                                // the caller's buffers are free again
+  c->src_type = c->up_type; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = c->up_attr != 0; c->built = false;
+  c->posattr_valid = false; c->bbox_guess_ok = true;
+  c->up_type = -1;
+  release(c, c->up_rgb); release(c, c->up_nrm);
+  return rebuild(c);
 }
 
 // ---- texture bake (pt_bake.hip) ------------------------------------------------------------------------------------

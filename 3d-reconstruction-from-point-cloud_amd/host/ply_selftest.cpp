@@ -2,7 +2,9 @@
 // src/pointsTransfer.cpp:134-253, :266-455) and on malformed input.  Built with -fsanitize=address,undefined by the CPU
 // test-suite; exit code 0 = all good.
 #include <cstdio>
+#include <algorithm>
 #include <fstream>
+#include <mutex>
 #include <random>
 #include <string>
 
@@ -107,6 +109,97 @@ int main(int argc, char** argv) {
     check_cloud(write(dir, "t.ply", "ply\nelement vertex 500\nend_header\n" + body(20000, 9)));                 // more than declared
     check_mesh(write(dir, "u.ply", "ply\nelement vertex 7000\nelement face 9000\nend_header\n" + body(7000, 11) + body(9000, 4)));
     check_mesh(write(dir, "v.ply", "ply\nelement vertex 7000\nelement face 9000\nend_header\n" + body(7000, 11) + body(100, 4) + "3 1"));
+  }
+  {   // ---- planar (SoA) output and binary little-endian files: same values as the record readers, range callbacks cover every record once ----
+    auto soa_equals = [&](const std::string& path, const std::vector<Point>& want, long want_declared, bool floats) {
+      for (int th : {1, -3, -16, 0}) {
+        ply::CloudSoA got;
+        std::vector<void*> mem;
+        std::vector<int> seen;
+        std::mutex mu;
+        long dg = 0;
+        const bool ok = ply::read_cloud_soa(path, got, dg, [&](size_t bytes) { void* q = std::malloc(bytes ? bytes : 1); mem.push_back(q); return q; },
+                                            [&](uint64_t n) { seen.assign((size_t)n, 0); return true; },
+                                            [&](uint64_t first, uint64_t count) { std::lock_guard<std::mutex> lk(mu); for (uint64_t i = first; i < first + count; ++i) ++seen[(size_t)i]; }, th);
+        CHECK(ok && dg == want_declared && got.n == want.size());
+        for (size_t i = 0; i < want.size() && i < got.n; ++i) {
+          const Point& w = want[i];
+          auto f = [&](double v) { return floats ? (double)(float)v : v; };
+          const bool same = eq(got.x[i], f(w.ver[0])) && eq(got.y[i], f(w.ver[1])) && eq(got.z[i], f(w.ver[2])) && eq(got.nrm[3 * i], (float)w.normal[0]) &&
+                            eq(got.nrm[3 * i + 1], (float)w.normal[1]) && eq(got.nrm[3 * i + 2], (float)w.normal[2]) &&
+                            got.rgb[3 * i] == std::min(std::max(w.color[0], 0), 255) && got.rgb[3 * i + 1] == std::min(std::max(w.color[1], 0), 255) &&
+                            got.rgb[3 * i + 2] == std::min(std::max(w.color[2], 0), 255);
+          if (!same) { CHECK(!"planar record differs"); break; }
+        }
+        for (int c : seen) if (c != 1) { CHECK(!"a record was reported by the range callback zero or several times"); break; }
+        for (void* q : mem) std::free(q);
+      }
+    };
+    std::vector<Point> want;
+    long dw = 0;
+    for (const char* f : {"a.ply", "b.ply", "q.ply", "r.ply", "s.ply", "t.ply"}) {
+      CHECK(ply::read_cloud(dir + "/" + f, want, dw));
+      soa_equals(dir + "/" + f, want, dw, false);
+    }
+    // binary: the records of r.ply written as (double xyz, float normals, uchar colours) and as all-float properties + two extra ones
+    CHECK(ply::read_cloud(dir + "/r.ply", want, dw));
+    for (Point& q : want) for (int a = 0; a < 3; ++a) { q.color[a] = std::min(std::max(q.color[a], 0), 255); if (q.ver[a] != q.ver[a]) q.ver[a] = 0; if (q.normal[a] != q.normal[a]) q.normal[a] = 0; }
+    {
+      std::string b = "ply\nformat binary_little_endian 1.0\nelement vertex " + std::to_string(want.size()) +
+                      "\nproperty double x\nproperty double y\nproperty double z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+                      "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n";
+      for (const Point& q : want) {
+        b.append(reinterpret_cast<const char*>(q.ver), 24);
+        for (int a = 0; a < 3; ++a) { const float v = (float)q.normal[a]; b.append(reinterpret_cast<const char*>(&v), 4); }
+        for (int a = 0; a < 3; ++a) b.push_back((char)(unsigned char)q.color[a]);
+      }
+      soa_equals(write(dir, "bin_d.ply", b), want, (long)want.size(), false);
+      b.resize(b.size() - 17);                                      // truncated: the last record is incomplete
+      std::vector<Point> fewer(want.begin(), want.end() - 1);
+      soa_equals(write(dir, "bin_t.ply", b), fewer, (long)want.size(), false);
+    }
+    {
+      std::string b = "ply\nformat binary_little_endian 1.0\ncomment all floats\nelement vertex " + std::to_string(want.size()) +
+                      "\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+                      "property ushort red\nproperty int green\nproperty uchar blue\nproperty float quality\nproperty uchar flag\nend_header\r\n";
+      for (const Point& q : want) {
+        for (int a = 0; a < 3; ++a) { const float v = (float)q.ver[a]; b.append(reinterpret_cast<const char*>(&v), 4); }
+        for (int a = 0; a < 3; ++a) { const float v = (float)q.normal[a]; b.append(reinterpret_cast<const char*>(&v), 4); }
+        const uint16_t r = (uint16_t)q.color[0]; const int32_t g = q.color[1]; const unsigned char bl = (unsigned char)q.color[2];
+        b.append(reinterpret_cast<const char*>(&r), 2); b.append(reinterpret_cast<const char*>(&g), 4); b.push_back((char)bl);
+        const float qual = 0.5f; b.append(reinterpret_cast<const char*>(&qual), 4); b.push_back((char)7);
+      }
+      soa_equals(write(dir, "bin_f.ply", b), want, (long)want.size(), true);
+    }
+    {   // binary mesh against the text mesh u.ply (cleaned of NaNs), faces with a quad in between (first three indices kept)
+      ply::Mesh tm;
+      CHECK(ply::read_mesh(dir + "/u.ply", tm));
+      std::string b = "ply\nformat binary_little_endian 1.0\nelement vertex " + std::to_string(tm.vertices.size()) +
+                      "\nproperty double x\nproperty double y\nproperty double z\nproperty double nx\nproperty double ny\nproperty double nz\n"
+                      "property double s\nproperty double t\nproperty int red\nproperty int green\nproperty int blue\nelement face " +
+                      std::to_string(tm.faces.size() / 3) + "\nproperty list uchar int vertex_indices\nend_header\n";
+      for (const Point& q : tm.vertices) {
+        b.append(reinterpret_cast<const char*>(q.ver), 24); b.append(reinterpret_cast<const char*>(q.normal), 24);
+        b.append(reinterpret_cast<const char*>(&q.U), 8); b.append(reinterpret_cast<const char*>(&q.V), 8);
+        b.append(reinterpret_cast<const char*>(q.color), 12);
+      }
+      for (size_t f = 0; f < tm.faces.size() / 3; ++f) {
+        const bool quad = f % 5 == 2;
+        b.push_back(quad ? 4 : 3);
+        b.append(reinterpret_cast<const char*>(&tm.faces[3 * f]), 12);
+        if (quad) { const int extra = 123; b.append(reinterpret_cast<const char*>(&extra), 4); }
+      }
+      const std::string path = write(dir, "bin_m.ply", b);
+      for (int th : {1, -5, 0}) {
+        ply::FastMesh got;
+        CHECK(ply::read_mesh_any(path, got, th));
+        CHECK(got.vertices.size() == tm.vertices.size() && got.faces == tm.faces);
+        for (size_t i = 0; i < tm.vertices.size() && i < got.vertices.size(); ++i)
+          if (!same_point(got.vertices[i], tm.vertices[i], true)) { CHECK(!"binary mesh vertex differs"); break; }
+      }
+      ply::FastMesh viaany;
+      CHECK(ply::read_mesh_any(dir + "/u.ply", viaany, 0) && viaany.faces == tm.faces);     // text files take the text path
+    }
   }
   std::printf(fails ? "ply selftest: %d failure(s)\n" : "ply selftest ok\n", fails);
   return fails ? 1 : 0;

@@ -203,6 +203,23 @@ int  pt_pack_requests_dev(pt_ctx*, const void* tgt_xyz_dev, int xyz_type, const 
 int  pt_query_bounded_dev(pt_ctx*, const void* xyz_dev, int xyz_type, const double* bound2_dev, uint64_t m,
                           int k, uint32_t* idx_dev, double* d2_dev);
 
+/* ---- streamed upload of a planar cloud: what a file reader feeds while it is still parsing ---------
+ * Replaces the copy of the points into the tree, `Tree tree(points.begin(), points.end())` (src/pointsTransfer.cpp:259),
+ * for callers that hold x[] y[] z[] (+ rgb, normals) instead of 80-byte records: 39 bytes per point cross PCIe instead of 80.
+ *   pt_host_alloc / pt_host_free   page-locked host memory (what makes the copies below asynchronous)
+ *   pt_upload_begin                reserve a cloud of n points of xyz_type (PT_F32 / PT_F64), with or without attributes
+ *   pt_upload_range                enqueue records [first, first + count): x, y, z point at `count` coordinates each,
+ *                                  rgb at count * 3 bytes, nrm at count * 3 floats (both may be NULL when begun without
+ *                                  attributes).  Thread-safe: parser threads call it as their ranges complete.  The memory
+ *                                  must stay valid until pt_upload_end returns.
+ *   pt_upload_end                  wait for the copies, pack the attribute table and build the grid (as pt_build_soa). */
+void* pt_host_alloc(uint64_t bytes);
+void  pt_host_free(void*);
+int   pt_upload_begin(pt_ctx*, uint64_t n, int xyz_type, int with_attributes);
+int   pt_upload_range(pt_ctx*, uint64_t first, uint64_t count, const void* x, const void* y, const void* z,
+                      const uint8_t* rgb, const float* nrm);
+int   pt_upload_end(pt_ctx*);
+
 /* ---- texture bake: the consumer of the neighbour lists -------------------------------------
  * pt_bake_texture replaces the body of the reference's face loop after the search and its rasteriser
  * (src/pointsTransfer.cpp:466-581 and draw_triangle :66-107): per face, the union of its three corners' neighbour

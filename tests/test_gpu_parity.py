@@ -839,14 +839,29 @@ def _read_png_rgba(path):
     return raw[:, 1:].reshape(h, w, 4)
 
 
-def test_cli_writes_the_texture(tmp_path, pkg, oracle):
-    """pointsTransfer cloud.ply mesh.ply -> texture.png (reference src/pointsTransfer.cpp:613-615): search (K = 20), per-face bake,
-    25 x 25 edge padding and PNG writing, end to end through the C++ host, decoded and compared with the oracle's atlas."""
-    import os, subprocess
-    from _bake_cases import make_case
-    src, rgb, verts, uv, vrgb, faces = make_case(9, n=8000, grid=5)
+def _write_binary_plys(pc, mesh, src, rgb, verts, uv, vrgb, faces):
+    """binary little-endian PLY files: cloud (double xyz, float normals, uchar colours), mesh (double x y z nx ny nz s t, int colours,
+    list uchar int faces)"""
     n, m = src.shape[1], verts.shape[1]
-    pc, mesh = tmp_path / "cloud.ply", tmp_path / "mesh.ply"
+    cd = np.dtype([("p", "<f8", 3), ("n", "<f4", 3), ("c", "u1", 3)])
+    a = np.zeros(n, cd); a["p"] = src.T; a["n"] = (0, 0, 1); a["c"] = rgb
+    with open(pc, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty double x\nproperty double y\nproperty double z\n"
+                 "property float nx\nproperty float ny\nproperty float nz\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % n).encode())
+        f.write(a.tobytes())
+    md = np.dtype([("p", "<f8", 3), ("n", "<f8", 3), ("uv", "<f8", 2), ("c", "<i4", 3)])
+    b = np.zeros(m, md); b["p"] = verts.T; b["n"] = (0, 0, 1); b["uv"] = uv; b["c"] = vrgb
+    fd = np.dtype([("k", "u1"), ("v", "<i4", 3)])
+    fc = np.zeros(len(faces), fd); fc["k"] = 3; fc["v"] = faces
+    with open(mesh, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty double x\nproperty double y\nproperty double z\n"
+                 "property double nx\nproperty double ny\nproperty double nz\nproperty double s\nproperty double t\nproperty int red\n"
+                 "property int green\nproperty int blue\nelement face %d\nproperty list uchar int vertex_indices\nend_header\n" % (m, len(faces))).encode())
+        f.write(b.tobytes()); f.write(fc.tobytes())
+
+
+def _write_ascii_plys(pc, mesh, src, rgb, verts, uv, vrgb, faces):
+    n, m = src.shape[1], verts.shape[1]
     with open(pc, "w") as f:
         f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\n"
                 "property float ny\nproperty float nz\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % n)
@@ -860,6 +875,18 @@ def test_cli_writes_the_texture(tmp_path, pkg, oracle):
             f.write("%.17g %.17g %.17g 0 0 1 %.17g %.17g %d %d %d\n" % (*verts[:, i], *uv[i], *vrgb[i]))
         for fc in faces:
             f.write("3 %d %d %d\n" % tuple(fc))
+
+
+@pytest.mark.parametrize("fmt", ["ascii", "binary"])
+def test_cli_writes_the_texture(tmp_path, pkg, oracle, fmt):
+    """pointsTransfer cloud.ply mesh.ply -> texture.png (reference src/pointsTransfer.cpp:613-615): search (K = 20), per-face bake,
+    25 x 25 edge padding and PNG writing, end to end through the C++ host, decoded and compared with the oracle's atlas -- from the
+    reference's ASCII files and from binary little-endian ones (the cloud reaches the GPU as planar arrays either way)."""
+    import os, subprocess
+    from _bake_cases import make_case
+    src, rgb, verts, uv, vrgb, faces = make_case(9, n=8000, grid=5)
+    pc, mesh = tmp_path / "cloud.ply", tmp_path / "mesh.ply"
+    (_write_ascii_plys if fmt == "ascii" else _write_binary_plys)(pc, mesh, src, rgb, verts, uv, vrgb, faces)
     exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "pointsTransfer")
     R = 640
     r = subprocess.run([exe, str(pc), str(mesh), "--resolution", str(R), "--out", ""], capture_output=True, text=True, cwd=tmp_path)
@@ -870,3 +897,35 @@ def test_cli_writes_the_texture(tmp_path, pkg, oracle):
     want = oracle.dilate_pad(oracle.bake_texture(src, rgb, verts, uv, vrgb, faces, idx, R), 25)
     assert got.shape == (R, R, 4)
     assert np.array_equal(got[:, :, [2, 1, 0, 3]], want)                  # the file holds R, G, B, A; the atlas is B, G, R, A
+
+
+def test_streamed_planar_upload_equals_build_soa(pkg, oracle):
+    """pt_upload_begin / pt_upload_range / pt_upload_end (the CLI's ingest: page-locked planar arrays, ranges uploaded as the parser
+    finishes them) builds the same cloud as pt_build_soa: same neighbours, same blended attributes."""
+    import ctypes as C
+    L = pkg.capi.lib()
+    rng = np.random.default_rng(21)
+    n, m, k = 70000, 3000, 8
+    src = rng.random((3, n)); rgb = rng.integers(0, 256, (n, 3), dtype=np.uint8); nrm = rng.standard_normal((n, 3)).astype(np.float32)
+    tgt = rng.random((3, m))
+    with pkg.PointsTransfer(device=0) as a, pkg.PointsTransfer(device=0) as b:
+        a.build(src, rgb, nrm)
+        wi, wd = a.query(tgt, k); wc, wn = a.blend(wi, wd)
+        sizes = [n * 8, n * 8, n * 8, n * 3, n * 12]
+        ptrs = [L.pt_host_alloc(sz) for sz in sizes]
+        assert all(ptrs)
+        for q, arr in zip(ptrs, [src[0], src[1], src[2], rgb, nrm]):
+            C.memmove(q, np.ascontiguousarray(arr).ctypes.data, arr.nbytes)
+        assert L.pt_upload_begin(b._h, n, pkg.F64, 1) == 0
+        cuts = [0, 1, 999, 1000, 31337, n]
+        for f0, f1 in reversed(list(zip(cuts[:-1], cuts[1:]))):             # ranges in any order
+            assert L.pt_upload_range(b._h, f0, f1 - f0, ptrs[0] + 8 * f0, ptrs[1] + 8 * f0, ptrs[2] + 8 * f0, ptrs[3] + 3 * f0, ptrs[4] + 12 * f0) == 0
+        assert L.pt_upload_range(b._h, n - 1, 5, ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4]) == pkg.capi.ERR_ARG      # beyond the cloud
+        assert L.pt_upload_end(b._h) == 0
+        for q in ptrs:
+            L.pt_host_free(q)
+        gi, gd = b.query(tgt, k); gc, gn = b.blend(gi, gd)
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd) and np.array_equal(gc, wc) and np.array_equal(gn, wn)
+        assert L.pt_upload_end(b._h) == pkg.capi.ERR_STATE                   # no upload in progress
+    ri, rd = oracle.knn_bruteforce(src, tgt, k)
+    assert np.array_equal(wi, ri) and np.array_equal(wd, rd)
