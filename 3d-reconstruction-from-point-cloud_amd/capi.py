@@ -23,7 +23,7 @@ SYMBOLS = [
     "pt_num_source", "pt_query_aos", "pt_query_soa", "pt_targets_synth", "pt_targets_soa", "pt_targets_aos", "pt_num_targets", "pt_query_resident", "pt_query_blend_resident",
     "pt_resident_target_ids", "pt_resident_target_xyz", "pt_blend", "pt_blend_dev", "pt_blend_weighted", "pt_blend_weighted_dev", "pt_pca_normals",
     "pt_pca_normals_dev", "pt_merge_candidates_dev", "pt_slab_need_dev", "pt_pack_requests_dev", "pt_query_bounded_dev",
-    "pt_bake_texture", "pt_texture_pad", "pt_host_alloc", "pt_host_free", "pt_upload_begin", "pt_upload_range", "pt_upload_end",
+    "pt_bake_texture", "pt_texture_pad", "pt_host_alloc", "pt_host_free", "pt_upload_begin", "pt_upload_range", "pt_upload_end", "pt_stream_query",
 ]
 
 
@@ -103,6 +103,7 @@ def lib():
         "pt_upload_begin": (i32, [p, u64, i32, i32]),
         "pt_upload_range": (i32, [p, u64, u64, p, p, p, p, p]),
         "pt_upload_end": (i32, [p]),
+        "pt_stream_query": (i32, [p, p, i32, u64, u64, u64, i32, p, p]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <vector>
 
 #include "../../include/pt_api.h"
 #include "pt_internal.h"
@@ -1060,6 +1061,90 @@ int pt_upload_end(pt_ctx* c) {
   c->up_type = -1;
   release(c, c->up_rgb); release(c, c->up_nrm);
   return rebuild(c);
+}
+
+// ---- out-of-core source --------------------------------------------------------------------------------------------
+int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64_t chunk_points, uint64_t first_id, int k, uint64_t* idx64_out,
+                    double* d2_out) {
+  if (!c) return PT_ERR_ARG;
+  if (xyz_type != PT_F32 && xyz_type != PT_F64) return fail(c, PT_ERR_ARG, "pt_stream_query: xyz_type must be PT_F32 or PT_F64");
+  if (c->tgt_type < 0) return fail(c, PT_ERR_STATE, "no resident targets (pt_targets_* first)");
+  if (c->tgt_type != xyz_type) return fail(c, PT_ERR_UNSUPPORTED, "target xyz type %d differs from the cloud's %d", c->tgt_type, xyz_type);
+  if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k = %d out of range [1, %d]", k, PT_MAX_K);
+  if (chunk_points < 1) return fail(c, PT_ERR_ARG, "chunk_points must be positive");
+  if ((n && !xyz) || (c->m && (!idx64_out || !d2_out))) return fail(c, PT_ERR_ARG, "null argument");
+  chunk_points = std::min<uint64_t>(chunk_points, 0xFFFFFFF0ull - 1);
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t m = c->m;
+  const size_t ts = tsize(xyz_type), lists = std::max<uint64_t>(m, 1) * (size_t)k;
+  const uint64_t nchunks = n ? (n + chunk_points - 1) / chunk_points : 0;
+  DevBuf best_i[2], best_d[2], ci, cd, stage[2];
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+  const int sync_save = c->sync;
+  DevBuf keep_in = c->in_xyz;                       // the context's own input buffer: put back at the end (the chunks live in `stage`)
+  auto cleanup = [&]() {
+    c->in_xyz = keep_in;
+    c->sync = sync_save;
+    DevBuf* all[] = {&best_i[0], &best_i[1], &best_d[0], &best_d[1], &ci, &cd, &stage[0], &stage[1]};
+    for (DevBuf* b : all) release(c, *b);
+    for (auto& e : copied) if (e) (void)hipEventDestroy(e);
+    for (auto& e : consumed) if (e) (void)hipEventDestroy(e);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+  };
+  auto run = [&]() -> int {
+    for (int b = 0; b < 2; ++b) { RES(c, best_i[b], lists * 8); RES(c, best_d[b], lists * 8); }
+    RES(c, ci, lists * 4); RES(c, cd, lists * 8);
+    HIPCHK(c, hipMemsetAsync(best_i[0].p, 0xFF, lists * 8, c->stream));                          // ~0 = no neighbour yet
+    HIPCHK(c, hipMemsetAsync(best_d[0].p, 0x7F, lists * 8, c->stream));    // (never compared: the merge reads a distance only beside a valid id)
+    HIPCHK(c, hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+      RES(c, stage[b], std::max<uint64_t>(std::min<uint64_t>(chunk_points, std::max<uint64_t>(n, 1)), 1) * 3 * ts);
+      HIPCHK(c, hipEventCreateWithFlags(&copied[b], hipEventDisableTiming));
+      HIPCHK(c, hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
+    }
+    auto upload = [&](uint64_t ch) -> int {          // chunk ch -> stage[ch & 1], planar with the chunk's own length as the stride
+      const int b = (int)(ch & 1);
+      const uint64_t f0 = ch * chunk_points, cnt = std::min<uint64_t>(chunk_points, n - f0);
+      HIPCHK(c, hipStreamWaitEvent(copy_stream, consumed[b], 0));      // (a never-recorded event does not block)
+      for (int a = 0; a < 3; ++a)
+        HIPCHK(c, hipMemcpyAsync((char*)stage[b].p + (size_t)a * cnt * ts, (const char*)xyz + ((size_t)a * n + f0) * ts, cnt * ts, hipMemcpyHostToDevice, copy_stream));
+      HIPCHK(c, hipEventRecord(copied[b], copy_stream));
+      return PT_OK;
+    };
+    c->sync = 1;
+    int cur = 0;
+    if (nchunks) { int r = upload(0); if (r) return r; }
+    for (uint64_t ch = 0; ch < nchunks; ++ch) {
+      const int b = (int)(ch & 1);
+      const uint64_t f0 = ch * chunk_points, cnt = std::min<uint64_t>(chunk_points, n - f0);
+      if (ch + 1 < nchunks) { int r = upload(ch + 1); if (r) return r; }          // the next chunk travels while this one is searched
+      HIPCHK(c, hipStreamWaitEvent(c->stream, copied[b], 0));
+      c->in_xyz = stage[b];
+      c->src_type = xyz_type; c->n = cnt; c->n_total = cnt; c->has_gidx = false; c->has_attr = false; c->built = false;
+      c->posattr_valid = false; c->bbox_guess_ok = true;
+      { int r = rebuild(c); if (r) return r; }
+      HIPCHK(c, hipEventRecord(consumed[b], c->stream));               // the build no longer reads stage[b] (records hold the coordinates)
+      { int r = run_query(c, c->t_xyz.p, c->tgt_type, m, k, nullptr, (uint32_t*)ci.p, (double*)cd.p); if (r) return r; }
+      pt_launch_merge_stream((const unsigned long long*)best_i[cur].p, (const double*)best_d[cur].p, (const uint32_t*)ci.p, (const double*)cd.p,
+                             (unsigned long long)(first_id + f0), (uint32_t)m, k, (unsigned long long*)best_i[cur ^ 1].p, (double*)best_d[cur ^ 1].p, c->stream);
+      HIPCHK(c, hipGetLastError());
+      cur ^= 1;
+    }
+    if (m) {
+      HIPCHK(c, hipMemcpyAsync(idx64_out, best_i[cur].p, (size_t)m * k * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(d2_out, best_d[cur].p, (size_t)m * k * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(copy_stream));
+    if (m && !nchunks) for (size_t i = 0; i < (size_t)m * k; ++i) d2_out[i] = std::numeric_limits<double>::infinity();
+    return PT_OK;
+  };
+  const int r = run();
+  cleanup();
+  // the chunks are gone with the stage buffers: no source cloud is resident any more (a later query needs a pt_build_* first)
+  c->n = 0; c->n_total = 0; c->built = false; c->src_type = -1; c->has_attr = false;
+  return r;
 }
 
 // ---- texture bake (pt_bake.hip) ------------------------------------------------------------------------------------

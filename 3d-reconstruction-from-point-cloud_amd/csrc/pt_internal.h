@@ -68,6 +68,9 @@ void pt_launch_request_pack(const T* x, const T* y, const T* z, const double* d2
                             int my_slab, uint32_t* count, uint32_t* sel, double* pkt, hipStream_t s);
 void pt_launch_merge(const uint32_t* idx_lists, const double* d2_lists, int g, uint32_t m, int k, uint32_t* idx_out,
                      double* d2_out, hipStream_t s);
+// streamed sources: merge the running best lists (u64 ids) with one chunk's lists (chunk-local u32 ids + base), out of place
+void pt_launch_merge_stream(const unsigned long long* best_idx, const double* best_d2, const uint32_t* chunk_idx, const double* chunk_d2,
+                            unsigned long long base, uint32_t m, int k, unsigned long long* out_idx, double* out_d2, hipStream_t s);
 template <class T>
 void pt_launch_slab_need(const T* x, const T* y, const T* z, const double* d2, uint32_t m, int k, int axis,
                          const double* bounds_dev, int g, int my_slab, uint8_t* need, hipStream_t s);

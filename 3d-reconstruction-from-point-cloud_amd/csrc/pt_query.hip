@@ -955,6 +955,28 @@ __global__ __launch_bounds__(WG) void merge_kernel(const uint32_t* __restrict__ 
   if (slot < k && slot >= cnt) { idx_out[(size_t)t * k + slot] = PT_NOIDX_U; d2_out[(size_t)t * k + slot] = INFINITY; }
 }
 
+// ---- running merge of a streamed source (pt_stream_query): the k best so far (64-bit ids) with the k of the chunk just searched
+// (32-bit chunk-local ids + the chunk's first id), both ascending under (d2, id); one thread per target, out-of-place
+__global__ __launch_bounds__(WG) void merge_stream_kernel(const unsigned long long* __restrict__ bi, const double* __restrict__ bd,
+                                                          const uint32_t* __restrict__ ci, const double* __restrict__ cd, unsigned long long base,
+                                                          uint32_t m, int k, unsigned long long* __restrict__ oi, double* __restrict__ od) {
+  const uint32_t t = blockIdx.x * WG + threadIdx.x;
+  if (t >= m) return;
+  const size_t row = (size_t)t * (size_t)k;
+  int a = 0, b = 0;
+  for (int o = 0; o < k; ++o) {
+    const bool ha = a < k && bi[row + a] != ~0ull, hb = b < k && ci[row + b] != PT_NOIDX_U;
+    unsigned long long ia = ~0ull, ib = ~0ull;
+    double da = INFINITY, db = INFINITY;
+    if (ha) { ia = bi[row + a]; da = bd[row + a]; }
+    if (hb) { ib = base + (unsigned long long)ci[row + b]; db = cd[row + b]; }
+    const bool take_a = ha && (!hb || da < db || (da == db && ia < ib));
+    if (take_a) { oi[row + o] = ia; od[row + o] = da; ++a; }
+    else if (hb) { oi[row + o] = ib; od[row + o] = db; ++b; }
+    else { oi[row + o] = ~0ull; od[row + o] = INFINITY; }
+  }
+}
+
 // ---- which other slabs can still hold one of a target's k nearest (reference Distance.h:27-57 on slab boxes)
 template <class T>
 __global__ __launch_bounds__(WG) void slab_need_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z,
@@ -1071,6 +1093,12 @@ void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* c
   }
 #undef PT_TILE_LAUNCH
 #undef PT_TILE_LAUNCH1
+}
+
+void pt_launch_merge_stream(const unsigned long long* best_idx, const double* best_d2, const uint32_t* chunk_idx, const double* chunk_d2,
+                           unsigned long long base, uint32_t m, int k, unsigned long long* out_idx, double* out_d2, hipStream_t s) {
+  if (!m) return;
+  hipLaunchKernelGGL(merge_stream_kernel, dim3((m + WG - 1) / WG), dim3(WG), 0, s, best_idx, best_d2, chunk_idx, chunk_d2, base, m, k, out_idx, out_d2);
 }
 
 void pt_launch_merge(const uint32_t* idx_lists, const double* d2_lists, int g, uint32_t m, int k, uint32_t* idx_out, double* d2_out,

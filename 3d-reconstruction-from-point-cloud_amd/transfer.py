@@ -240,6 +240,16 @@ class PointsTransfer:
         self._adopt_torch_stream()
         self._chk(self._L.pt_pca_normals_dev(self._h, _ptr(idx_dev), m, k, _ptr(nrm_out_dev)))
 
+    # -- out-of-core source (README.md:3 "billions of points") ---------------------------------------
+    def stream_query(self, xyz, chunk_points, k=K_REFERENCE, first_id=0, xyz_type=None):
+        """k-NN of the RESIDENT targets in a cloud kept in host memory and streamed through the GPU chunk by chunk;
+        returns (idx uint64 (m, k), d2 (m, k)) -- indices are first_id + position in `xyz`."""
+        a, t = _planar(xyz, xyz_type)
+        m = self.num_targets
+        idx = np.empty((m, k), np.uint64); d2 = np.empty((m, k), np.float64)
+        self._chk(self._L.pt_stream_query(self._h, _ptr(a), t, a.shape[1], int(chunk_points), int(first_id), k, _ptr(idx), _ptr(d2)))
+        return idx, d2
+
     # -- texture bake (pointsTransfer.cpp:466-615) ------------------------------------------------
     def bake_texture(self, mesh_vertices, faces, nbr_idx, resolution=8192, pad_ksize=0):
         """mesh_vertices: POINT_DTYPE records (ver, color, U, V are read); faces: int32 (F, 3); nbr_idx: uint32 (V, k) from a

@@ -220,6 +220,17 @@ int   pt_upload_range(pt_ctx*, uint64_t first, uint64_t count, const void* x, co
                       const uint8_t* rgb, const float* nrm);
 int   pt_upload_end(pt_ctx*);
 
+/* ---- out-of-core source (reference README.md:3 "billions of points") ------------------------------------
+ * Searches the RESIDENT targets (pt_targets_*) in a cloud that stays in host memory: the cloud is cut into chunks of
+ * `chunk_points` consecutive points, every chunk is uploaded (the next one while the current one is being searched: keep
+ * `xyz` in page-locked memory, pt_host_alloc, for that overlap), gridded and searched like a resident cloud, and the k best
+ * of the chunk are merged into the running k best under the same total order (d2, index).  Indices are 64-bit -- a streamed
+ * cloud may hold more than 2^32 points -- and are `first_id` + the point's position in `xyz`.  The result is bit-identical to
+ * a resident search of the whole cloud.  xyz: planar, n points of xyz_type (PT_F32 / PT_F64; the targets' type);
+ * idx64_out / d2_out: host, [m][k].  The context's resident cloud is replaced (by the last chunk). */
+int  pt_stream_query(pt_ctx*, const void* xyz, int xyz_type, uint64_t n, uint64_t chunk_points, uint64_t first_id, int k,
+                     uint64_t* idx64_out, double* d2_out);
+
 /* ---- texture bake: the consumer of the neighbour lists -------------------------------------
  * pt_bake_texture replaces the body of the reference's face loop after the search and its rasteriser
  * (src/pointsTransfer.cpp:466-581 and draw_triangle :66-107): per face, the union of its three corners' neighbour

@@ -929,3 +929,35 @@ def test_streamed_planar_upload_equals_build_soa(pkg, oracle):
         assert L.pt_upload_end(b._h) == pkg.capi.ERR_STATE                   # no upload in progress
     ri, rd = oracle.knn_bruteforce(src, tgt, k)
     assert np.array_equal(wi, ri) and np.array_equal(wd, rd)
+
+
+@pytest.mark.parametrize("dtype,nchunks", [(np.float32, 2), (np.float64, 3), (np.float32, 7)])
+def test_streamed_source_equals_resident(pkg, oracle, dtype, nchunks):
+    """a cloud kept in host memory and streamed through the GPU in chunks (each gridded and searched like a
+    resident cloud, the running k best merged under (d2, index)) gives the resident search's result bit for bit, with 64-bit ids."""
+    rng = np.random.default_rng(31)
+    n, m, k = 120_001, 4000, 20
+    src = rng.random((3, n)).astype(dtype)
+    src[:, 5000:5200] = src[:, :200]                                       # duplicates across chunk borders: ties broken by the global index
+    tgt = rng.random((3, m)).astype(dtype)
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.build(src)
+        wi, wd = p.query(tgt, k)
+        p.set_targets(tgt)
+        chunk = (n + nchunks - 1) // nchunks
+        gi, gd = p.stream_query(src, chunk, k)
+        assert np.array_equal(gi, wi.astype(np.uint64)) and np.array_equal(gd, wd)
+        base = (1 << 33) + 12345                                            # ids beyond 32 bits
+        gi2, gd2 = p.stream_query(src, chunk, k, first_id=base)
+        assert np.array_equal(gi2, wi.astype(np.uint64) + np.uint64(base)) and np.array_equal(gd2, wd)
+        with pytest.raises(pkg.PtError):                                     # the chunks are gone: nothing resident to query
+            p.query(tgt, k)
+        # k larger than a chunk, an empty cloud
+        small = src[:, :30]
+        p.build(small); si, sd = p.query(tgt[:, :50], 32); p.set_targets(tgt[:, :50])
+        ti, td = p.stream_query(small, 7, 32)
+        assert np.array_equal(ti[:, :30], si[:, :30].astype(np.uint64)) and (ti[:, 30:] == np.uint64(0xFFFFFFFFFFFFFFFF)).all() and np.isinf(td[:, 30:]).all()
+        ei, ed = p.stream_query(src[:, :0], 1000, 8)
+        assert (ei == np.uint64(0xFFFFFFFFFFFFFFFF)).all() and np.isinf(ed).all()
+    ri, rd = oracle.knn_bruteforce(src.astype(np.float64), tgt.astype(np.float64), k)
+    assert np.array_equal(wi, ri) and np.array_equal(wd, rd)
