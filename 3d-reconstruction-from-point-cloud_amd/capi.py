@@ -24,6 +24,7 @@ SYMBOLS = [
     "pt_resident_target_ids", "pt_resident_target_xyz", "pt_blend", "pt_blend_dev", "pt_blend_weighted", "pt_blend_weighted_dev", "pt_pca_normals",
     "pt_pca_normals_dev", "pt_merge_candidates_dev", "pt_slab_need_dev", "pt_pack_requests_dev", "pt_query_bounded_dev",
     "pt_bake_texture", "pt_texture_pad", "pt_host_alloc", "pt_host_free", "pt_upload_begin", "pt_upload_range", "pt_upload_end", "pt_stream_query",
+    "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_exchange_merge_dev", "pt_exchange_merge_local", "pt_query_exchange_blend",
 ]
 
 
@@ -38,6 +39,10 @@ class Stats(C.Structure):
         ("ms_kernel", C.c_double * 8), ("n_leftover", C.c_uint64), ("rho_occupied", C.c_double),
         ("n_refine", C.c_int32), ("bbox_guess", C.c_int32), ("ms_bake", C.c_double),
     ]
+
+
+class ExchangeStats(C.Structure):
+    _fields_ = [("crossing", C.c_uint64), ("answered", C.c_uint64), ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64), ("ms", C.c_double)]
 
 
 class PtError(RuntimeError):
@@ -104,6 +109,12 @@ def lib():
         "pt_upload_range": (i32, [p, u64, u64, p, p, p, p, p]),
         "pt_upload_end": (i32, [p]),
         "pt_stream_query": (i32, [p, p, i32, u64, u64, u64, i32, p, p]),
+        "pt_comm_unique_id": (i32, [p]),
+        "pt_comm_init": (i32, [p, i32, i32, p]),
+        "pt_comm_destroy": (i32, [p]),
+        "pt_exchange_merge_dev": (i32, [p, p, i32, u64, i32, i32, p, p, p, i32, p, p, p]),
+        "pt_exchange_merge_local": (i32, [p, i32, p, i32, p, i32, i32, p, p, p, i32, p, p]),
+        "pt_query_exchange_blend": (i32, [p, p, i32, u64, i32, i32, p, i32, p, p, p, p, p]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():

@@ -7,6 +7,8 @@
 //   pt_stats     <->  the timer lines                                     src/pointsTransfer.cpp:261,587
 // There is no CPU fallback anywhere in this file: without a usable HIP device every entry point fails.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: librccl is dlopen'ed by pt_comm_* (no link-time dependency)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -64,6 +66,13 @@ struct pt_ctx {
   DevBuf t_xyz, t_gidx, trec, trec_tmp;
   DevBuf x_xyz;                // transient targets of pt_query_soa / _aos / _bounded_dev (resident targets stay untouched)
   bool t_has_gidx = false;
+  // slab exchange (pt_comm_* / pt_exchange_*)
+  void* nccl_comm = nullptr;
+  hipEvent_t xev[2] = {nullptr, nullptr};                     // exchange timing (run_query uses ev[0..2] itself)
+  int world = 1, rank = 0;
+  DevBuf x_bounds, x_counts, x_matrix, x_off, x_req, x_row, x_rreq, x_rxyz, x_rbound, x_ans_i, x_ans_d, x_back_i, x_back_d, x_flags, x_rows;
+  std::vector<uint32_t> x_send, x_recv, x_soff, x_roff;      // per peer: packets to send / to answer, and their offsets
+  uint32_t* h_matrix = nullptr;                               // pinned, world * world
   // streamed upload (pt_upload_*)
   uint64_t up_n = 0;
   int up_type = -1, up_attr = 0;
@@ -531,6 +540,8 @@ int pt_ctx_create(pt_ctx** out, const int* device_ids, int n_devices) {
     if (hipEventCreate(&e) != hipSuccess) { delete c; return PT_ERR_HIP; }
   for (auto& e : c->sev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return PT_ERR_HIP; }
+  for (auto& e : c->xev)
+    if (hipEventCreate(&e) != hipSuccess) { delete c; return PT_ERR_HIP; }
   if (hipHostMalloc((void**)&c->h_bbox, 8 * sizeof(uint64_t)) != hipSuccess || hipHostMalloc((void**)&c->h_counter, 64) != hipSuccess) {
     delete c;
     return PT_ERR_HIP;
@@ -545,12 +556,16 @@ void pt_ctx_destroy(pt_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in_xyz, &c->in_gidx, &c->attr, &c->rec, &c->rec_tmp, &c->cell_start, &c->stb_mem, &c->t_xyz, &c->t_gidx, &c->trec,
-                   &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr, &c->retry, &c->rec32, &c->up_rgb, &c->up_nrm};
+                   &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr, &c->retry, &c->rec32, &c->up_rgb, &c->up_nrm, &c->x_bounds, &c->x_counts, &c->x_matrix, &c->x_off, &c->x_req, &c->x_row, &c->x_rreq,
+                   &c->x_rxyz, &c->x_rbound, &c->x_ans_i, &c->x_ans_d, &c->x_back_i, &c->x_back_d, &c->x_flags, &c->x_rows};
   for (DevBuf* b : all) release(c, *b);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);
+  if (c->h_matrix) (void)hipHostFree(c->h_matrix);
+  (void)pt_comm_destroy(c);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->sev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->xev) if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1145,6 +1160,311 @@ int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64
   // the chunks are gone with the stage buffers: no source cloud is resident any more (a later query needs a pt_build_* first)
   c->n = 0; c->n_total = 0; c->built = false; c->src_type = -1; c->has_attr = false;
   return r;
+}
+
+// ---- native slab exchange ----------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi* rccl() {          // loaded once, on first use
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (api.lib) break;
+    }
+    if (api.lib) {
+      auto sym = [&](const char* n) { return dlsym(api.lib, n); };
+      api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+      api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+      api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+      api.Send = (decltype(api.Send))sym("ncclSend");
+      api.Recv = (decltype(api.Recv))sym("ncclRecv");
+      api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+      api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+      api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+      if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd) {
+        dlclose(api.lib);
+        api.lib = nullptr;
+      }
+    }
+  }
+  return api.lib ? &api : nullptr;
+}
+#define NCCLCHK(c, call)                                                                                                      \
+  do {                                                                                                                        \
+    ncclResult_t r_ = (call);                                                                                                 \
+    if (r_ != ncclSuccess) return fail((c), PT_ERR_HIP, "%s failed: %s", #call, rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "rccl error"); \
+  } while (0)
+
+struct XArgs { const void* xyz; int type; uint32_t m; int k, axis, g, me; uint32_t* idx; double* d2; };
+
+// phase a: upload the slab bounds, count the crossing targets per destination slab into x_counts[g]
+int xa_count(pt_ctx* c, const XArgs& A, const double* bounds) {
+  RES(c, c->x_bounds, 65 * sizeof(double));
+  RES(c, c->x_counts, 64 * sizeof(uint32_t));
+  HIPCHK(c, hipMemcpyAsync(c->x_bounds.p, bounds, (size_t)(A.g + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->x_counts.p, 0, 64 * sizeof(uint32_t), c->stream));
+  if (A.type == PT_F32) { const float* x = (const float*)A.xyz; pt_launch_xreq<float>(false, x, x + A.m, x + 2 * (size_t)A.m, A.d2, A.m, A.k, A.axis, (const double*)c->x_bounds.p, A.g, A.me, (uint32_t*)c->x_counts.p, nullptr, nullptr, nullptr, nullptr, c->stream); }
+  else { const double* x = (const double*)A.xyz; pt_launch_xreq<double>(false, x, x + A.m, x + 2 * (size_t)A.m, A.d2, A.m, A.k, A.axis, (const double*)c->x_bounds.p, A.g, A.me, (uint32_t*)c->x_counts.p, nullptr, nullptr, nullptr, nullptr, c->stream); }
+  HIPCHK(c, hipGetLastError());
+  return PT_OK;
+}
+// phase b: with the count matrix on the host (matrix[r * g + s] = packets rank r sends to s), size the buffers and bucket the requests
+int xb_fill(pt_ctx* c, const XArgs& A, const uint32_t* matrix) {
+  const int g = A.g, me = A.me;
+  c->x_send.assign((size_t)g, 0); c->x_recv.assign((size_t)g, 0); c->x_soff.assign((size_t)g + 1, 0); c->x_roff.assign((size_t)g + 1, 0);
+  for (int p = 0; p < g; ++p) { c->x_send[(size_t)p] = matrix[(size_t)me * g + p]; c->x_recv[(size_t)p] = matrix[(size_t)p * g + me]; }
+  for (int p = 0; p < g; ++p) { c->x_soff[(size_t)p + 1] = c->x_soff[(size_t)p] + c->x_send[(size_t)p]; c->x_roff[(size_t)p + 1] = c->x_roff[(size_t)p] + c->x_recv[(size_t)p]; }
+  const size_t S = c->x_soff[(size_t)g], R = c->x_roff[(size_t)g];
+  RES(c, c->x_off, 2 * 65 * sizeof(uint32_t));
+  RES(c, c->x_req, std::max<size_t>(S, 1) * 32); RES(c, c->x_row, std::max<size_t>(S, 1) * 4);
+  RES(c, c->x_rreq, std::max<size_t>(R, 1) * 32);
+  RES(c, c->x_back_i, std::max<size_t>(S, 1) * (size_t)A.k * 4); RES(c, c->x_back_d, std::max<size_t>(S, 1) * (size_t)A.k * 8);
+  RES(c, c->x_ans_i, std::max<size_t>(R, 1) * (size_t)A.k * 4); RES(c, c->x_ans_d, std::max<size_t>(R, 1) * (size_t)A.k * 8);
+  uint32_t* off = (uint32_t*)c->x_off.p;
+  uint32_t* cursor = off + 65;
+  HIPCHK(c, hipMemcpyAsync(off, c->x_soff.data(), (size_t)(g + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(cursor, 0, 65 * sizeof(uint32_t), c->stream));
+  if (S) {
+    if (A.type == PT_F32) { const float* x = (const float*)A.xyz; pt_launch_xreq<float>(true, x, x + A.m, x + 2 * (size_t)A.m, A.d2, A.m, A.k, A.axis, (const double*)c->x_bounds.p, g, me, nullptr, off, cursor, (double*)c->x_req.p, (uint32_t*)c->x_row.p, c->stream); }
+    else { const double* x = (const double*)A.xyz; pt_launch_xreq<double>(true, x, x + A.m, x + 2 * (size_t)A.m, A.d2, A.m, A.k, A.axis, (const double*)c->x_bounds.p, g, me, nullptr, off, cursor, (double*)c->x_req.p, (uint32_t*)c->x_row.p, c->stream); }
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));       // (x_soff is host memory the copy above reads)
+  return PT_OK;
+}
+// phase c: answer the requests received (x_rreq, x_roff[g] of them) with a radius-bounded search of this rank's slab
+int xc_answer(pt_ctx* c, const XArgs& A) {
+  const uint32_t R = c->x_roff[(size_t)A.g];
+  if (!R) return PT_OK;
+  RES(c, c->x_rxyz, (size_t)R * 3 * tsize(A.type)); RES(c, c->x_rbound, (size_t)R * 8);
+  if (A.type == PT_F32) pt_launch_xunpack<float>((const double*)c->x_rreq.p, R, (float*)c->x_rxyz.p, (double*)c->x_rbound.p, c->stream);
+  else pt_launch_xunpack<double>((const double*)c->x_rreq.p, R, (double*)c->x_rxyz.p, (double*)c->x_rbound.p, c->stream);
+  return run_query(c, c->x_rxyz.p, A.type, R, A.k, (const double*)c->x_rbound.p, (uint32_t*)c->x_ans_i.p, (double*)c->x_ans_d.p);
+}
+// phase d: merge what came back (x_back_*, bucket by bucket) and redo the blend of the completed rows
+int xd_merge(pt_ctx* c, const XArgs& A, int blend_mode, float* rgb, float* nrm) {
+  const uint32_t S = c->x_soff[(size_t)A.g];
+  if (!S) return PT_OK;
+  const bool reblend = blend_mode >= 0 && (rgb || nrm) && c->has_attr;
+  uint8_t* flags = nullptr;
+  if (reblend) {
+    RES(c, c->x_flags, std::max<size_t>(A.m, 1)); RES(c, c->x_rows, (std::max<size_t>(A.m, 1) + 4) * 4);
+    flags = (uint8_t*)c->x_flags.p;
+    HIPCHK(c, hipMemsetAsync(flags, 0, A.m, c->stream));
+  }
+  for (int p = 0; p < A.g; ++p) {                     // one launch per bucket: a row may sit in two buckets (both neighbours)
+    const uint32_t cnt = c->x_send[(size_t)p], o = c->x_soff[(size_t)p];
+    pt_launch_xmerge((const uint32_t*)c->x_row.p + o, cnt, (const uint32_t*)c->x_back_i.p + (size_t)o * A.k, (const double*)c->x_back_d.p + (size_t)o * A.k, A.k,
+                     A.idx, A.d2, flags, c->stream);
+  }
+  if (reblend) {
+    uint32_t* rows = (uint32_t*)c->x_rows.p;
+    uint32_t* rows_n = rows + std::max<size_t>(A.m, 1);
+    HIPCHK(c, hipMemsetAsync(rows_n, 0, 4, c->stream));
+    pt_launch_xflag_rows(flags, A.m, rows, rows_n, c->stream);
+    pt_launch_blend_rows(rows, rows_n, std::min<uint32_t>(A.m, S), A.idx, A.d2, A.k, blend_mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, rgb, nrm, c->stream);
+  }
+  HIPCHK(c, hipGetLastError());
+  return PT_OK;
+}
+int xcheck(pt_ctx* c, int xyz_type, uint64_t m, int k, int axis, int g, const double* bounds, const void* xyz, const uint32_t* idx, const double* d2) {
+  if (xyz_type != PT_F32 && xyz_type != PT_F64) return fail(c, PT_ERR_UNSUPPORTED, "xyz_type %d not supported", xyz_type);
+  if (!c->built) return fail(c, PT_ERR_STATE, "exchange before build");
+  if (xyz_type != c->src_type) return fail(c, PT_ERR_UNSUPPORTED, "target xyz type %d differs from the source cloud's %d", xyz_type, c->src_type);
+  if (g < 1 || g > 64 || k < 1 || k > PT_MAX_K || axis < 0 || axis > 2) return fail(c, PT_ERR_ARG, "argument out of range");
+  if (!bounds || (m && (!xyz || !idx || !d2))) return fail(c, PT_ERR_ARG, "null argument");
+  return check_n(c, m, "m");
+}
+}  // namespace
+
+int pt_comm_unique_id(void* id_out) {
+  if (!id_out || !rccl()) return PT_ERR_HIP;
+  ncclUniqueId id;
+  if (rccl()->GetUniqueId(&id) != ncclSuccess) return PT_ERR_HIP;
+  static_assert(sizeof(ncclUniqueId) == PT_COMM_ID_BYTES, "RCCL unique id size");
+  memcpy(id_out, &id, sizeof id);
+  return PT_OK;
+}
+
+int pt_comm_init(pt_ctx* c, int world, int rank, const void* id) {
+  if (!c) return PT_ERR_ARG;
+  if (world < 1 || world > 64 || rank < 0 || rank >= world || !id) return fail(c, PT_ERR_ARG, "pt_comm_init: world / rank / id out of range");
+  if (c->nccl_comm) return fail(c, PT_ERR_STATE, "communicator already initialised");
+  if (!rccl()) return fail(c, PT_ERR_HIP, "librccl could not be loaded");
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  ncclComm_t comm = nullptr;
+  NCCLCHK(c, rccl()->CommInitRank(&comm, world, uid, rank));
+  c->nccl_comm = comm; c->world = world; c->rank = rank;
+  if (!c->h_matrix) HIPCHK(c, hipHostMalloc((void**)&c->h_matrix, 64 * 64 * sizeof(uint32_t)));
+  return PT_OK;
+}
+
+int pt_comm_destroy(pt_ctx* c) {
+  if (!c) return PT_ERR_ARG;
+  if (c->nccl_comm && rccl()) { (void)hipSetDevice(c->device); (void)rccl()->CommDestroy((ncclComm_t)c->nccl_comm); }
+  c->nccl_comm = nullptr; c->world = 1; c->rank = 0;
+  return PT_OK;
+}
+
+int pt_exchange_merge_dev(pt_ctx* c, const void* tgt_xyz_dev, int xyz_type, uint64_t m, int k, int slab_axis, const double* slab_bounds, uint32_t* idx_dev,
+                          double* d2_dev, int blend_mode, float* rgb_dev, float* nrm_dev, pt_exchange_stats_t* st) {
+  if (!c) return PT_ERR_ARG;
+  if (st) memset(st, 0, sizeof *st);
+  const int g = c->world, me = c->rank;
+  { int r = xcheck(c, xyz_type, m, k, slab_axis, g, slab_bounds, tgt_xyz_dev, idx_dev, d2_dev); if (r) return r; }
+  if (g == 1) return PT_OK;
+  if (!c->nccl_comm) return fail(c, PT_ERR_STATE, "pt_exchange_merge_dev before pt_comm_init");
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclComm_t comm = (ncclComm_t)c->nccl_comm;
+  const XArgs A{tgt_xyz_dev, xyz_type, (uint32_t)m, k, slab_axis, g, me, idx_dev, d2_dev};
+  const int sync_save = c->sync;
+  c->sync = 0;                                          // the bounded search only enqueues: no host wait between the phases
+  auto body = [&]() -> int {
+    HIPCHK(c, hipEventRecord(c->xev[0], c->stream));
+    { int r = xa_count(c, A, slab_bounds); if (r) return r; }
+    RES(c, c->x_matrix, 64 * 64 * sizeof(uint32_t));
+    NCCLCHK(c, rccl()->AllGather(c->x_counts.p, c->x_matrix.p, 64, ncclUint32, comm, c->stream));      // rows of 64 counters, g of them
+    HIPCHK(c, hipMemcpyAsync(c->h_matrix, c->x_matrix.p, (size_t)g * 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));         // the one host read-back: every later size follows from the matrix
+    std::vector<uint32_t> matrix((size_t)g * g);
+    for (int r = 0; r < g; ++r) for (int s2 = 0; s2 < g; ++s2) matrix[(size_t)r * g + s2] = c->h_matrix[(size_t)r * 64 + s2];
+    { int r = xb_fill(c, A, matrix.data()); if (r) return r; }
+    NCCLCHK(c, rccl()->GroupStart());
+    for (int p = 0; p < g; ++p) {
+      if (p == me) continue;
+      if (c->x_send[(size_t)p]) NCCLCHK(c, rccl()->Send((const double*)c->x_req.p + (size_t)c->x_soff[(size_t)p] * 4, (size_t)c->x_send[(size_t)p] * 4, ncclFloat64, p, comm, c->stream));
+      if (c->x_recv[(size_t)p]) NCCLCHK(c, rccl()->Recv((double*)c->x_rreq.p + (size_t)c->x_roff[(size_t)p] * 4, (size_t)c->x_recv[(size_t)p] * 4, ncclFloat64, p, comm, c->stream));
+    }
+    NCCLCHK(c, rccl()->GroupEnd());
+    { int r = xc_answer(c, A); if (r) return r; }
+    NCCLCHK(c, rccl()->GroupStart());
+    for (int p = 0; p < g; ++p) {
+      if (p == me) continue;
+      const size_t ro = (size_t)c->x_roff[(size_t)p] * k, rc = (size_t)c->x_recv[(size_t)p] * k, so = (size_t)c->x_soff[(size_t)p] * k, sc = (size_t)c->x_send[(size_t)p] * k;
+      if (rc) { NCCLCHK(c, rccl()->Send((const uint32_t*)c->x_ans_i.p + ro, rc, ncclUint32, p, comm, c->stream)); NCCLCHK(c, rccl()->Send((const double*)c->x_ans_d.p + ro, rc, ncclFloat64, p, comm, c->stream)); }
+      if (sc) { NCCLCHK(c, rccl()->Recv((uint32_t*)c->x_back_i.p + so, sc, ncclUint32, p, comm, c->stream)); NCCLCHK(c, rccl()->Recv((double*)c->x_back_d.p + so, sc, ncclFloat64, p, comm, c->stream)); }
+    }
+    NCCLCHK(c, rccl()->GroupEnd());
+    { int r = xd_merge(c, A, blend_mode, rgb_dev, nrm_dev); if (r) return r; }
+    HIPCHK(c, hipEventRecord(c->xev[1], c->stream));
+    return PT_OK;
+  };
+  const int r = body();
+  c->sync = sync_save;
+  if (r != PT_OK) return r;
+  if (st) {
+    const uint64_t S = c->x_soff[(size_t)g], R = c->x_roff[(size_t)g];
+    st->crossing = S; st->answered = R;
+    st->bytes_sent = S * 32 + R * (uint64_t)k * 12; st->bytes_received = R * 32 + S * (uint64_t)k * 12;
+  }
+  if (c->sync || st) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (st) { float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, c->xev[0], c->xev[1])); st->ms = ms; }
+  }
+  return PT_OK;
+}
+
+int pt_query_exchange_blend(pt_ctx* c, const void* tgt_xyz, int xyz_type, uint64_t m, int k, int slab_axis, const double* slab_bounds, int blend_mode,
+                            uint32_t* idx_out, double* d2_out, float* rgb_out, float* nrm_out, pt_exchange_stats_t* st) {
+  if (!c) return PT_ERR_ARG;
+  if (st) memset(st, 0, sizeof *st);
+  if (!c->built) return fail(c, PT_ERR_STATE, "query before build");
+  if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k = %d out of range [1, %d]", k, PT_MAX_K);
+  if (m && (!tgt_xyz || !idx_out || !d2_out)) return fail(c, PT_ERR_ARG, "null argument");
+  const bool blend = blend_mode >= 0 && (rgb_out || nrm_out);
+  if (blend && blend_mode != PT_BLEND_MEAN && blend_mode != PT_BLEND_INV_D2) return fail(c, PT_ERR_ARG, "unknown blend mode %d", blend_mode);
+  if (blend && !c->has_attr) return fail(c, PT_ERR_STATE, "no attribute table resident");
+  { int r = pt_targets_soa(c, tgt_xyz, xyz_type, m, 0); if (r) return r; }
+  if (c->tgt_type != c->src_type) return fail(c, PT_ERR_UNSUPPORTED, "target xyz type differs from the source cloud's");
+  RES(c, c->q_idx, std::max<uint64_t>(m, 1) * k * sizeof(uint32_t));
+  RES(c, c->q_d2, std::max<uint64_t>(m, 1) * k * sizeof(double));
+  RES(c, c->b_rgb, std::max<uint64_t>(m, 1) * 12);
+  RES(c, c->b_nrm, std::max<uint64_t>(m, 1) * 12);
+  const BlendReq br{blend_mode, (float*)c->b_rgb.p, (float*)c->b_nrm.p};
+  { int r = run_query(c, c->t_xyz.p, c->tgt_type, m, k, nullptr, (uint32_t*)c->q_idx.p, (double*)c->q_d2.p, blend ? &br : nullptr); if (r) return r; }
+  if (c->world > 1) {
+    int r = pt_exchange_merge_dev(c, c->t_xyz.p, c->tgt_type, m, k, slab_axis, slab_bounds, (uint32_t*)c->q_idx.p, (double*)c->q_d2.p, blend ? blend_mode : -1,
+                                  blend ? (float*)c->b_rgb.p : nullptr, blend ? (float*)c->b_nrm.p : nullptr, st);
+    if (r) return r;
+  }
+  if (m) {
+    HIPCHK(c, hipMemcpyAsync(idx_out, c->q_idx.p, m * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d2_out, c->q_d2.p, m * k * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (blend && rgb_out) HIPCHK(c, hipMemcpyAsync(rgb_out, c->b_rgb.p, m * 12, hipMemcpyDeviceToHost, c->stream));
+    if (blend && nrm_out) HIPCHK(c, hipMemcpyAsync(nrm_out, c->b_nrm.p, m * 12, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PT_OK;
+}
+
+int pt_exchange_merge_local(pt_ctx* const* ctxs, int g, const void* const* tgt_xyz_dev, int xyz_type, const uint64_t* m, int k, int slab_axis,
+                            const double* slab_bounds, uint32_t* const* idx_dev, double* const* d2_dev, int blend_mode, float* const* rgb_dev,
+                            float* const* nrm_dev) {
+  if (!ctxs || g < 1 || g > 64 || !tgt_xyz_dev || !m || !idx_dev || !d2_dev) return PT_ERR_ARG;
+  for (int r = 0; r < g; ++r) if (!ctxs[r]) return PT_ERR_ARG;
+  std::vector<XArgs> A((size_t)g);
+  std::vector<int> sync_save((size_t)g);
+  for (int r = 0; r < g; ++r) {
+    pt_ctx* c = ctxs[r];
+    { int e = xcheck(c, xyz_type, m[r], k, slab_axis, g, slab_bounds, tgt_xyz_dev[r], idx_dev[r], d2_dev[r]); if (e) return e; }
+    A[(size_t)r] = XArgs{tgt_xyz_dev[r], xyz_type, (uint32_t)m[r], k, slab_axis, g, r, idx_dev[r], d2_dev[r]};
+    sync_save[(size_t)r] = c->sync;
+  }
+  if (g == 1) return PT_OK;
+  auto restore = [&]() { for (int r = 0; r < g; ++r) ctxs[r]->sync = sync_save[(size_t)r]; };
+  auto all_sync = [&]() -> int { for (int r = 0; r < g; ++r) { pt_ctx* c = ctxs[r]; HIPCHK(c, hipStreamSynchronize(c->stream)); } return PT_OK; };
+  auto body = [&]() -> int {
+    std::vector<uint32_t> matrix((size_t)g * g, 0), row(64);
+    for (int r = 0; r < g; ++r) { int e = xa_count(ctxs[r], A[(size_t)r], slab_bounds); if (e) return e; }
+    for (int r = 0; r < g; ++r) {                                             // "all-gather" of the counters
+      pt_ctx* c = ctxs[r];
+      HIPCHK(c, hipMemcpyAsync(row.data(), c->x_counts.p, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      for (int s2 = 0; s2 < g; ++s2) matrix[(size_t)r * g + s2] = row[(size_t)s2];
+    }
+    for (int r = 0; r < g; ++r) { int e = xb_fill(ctxs[r], A[(size_t)r], matrix.data()); if (e) return e; }
+    for (int r = 0; r < g; ++r)                                               // requests, owner to owner
+      for (int p = 0; p < g; ++p) {
+        pt_ctx *a = ctxs[r], *b = ctxs[p];
+        if (p == r || !a->x_send[(size_t)p]) continue;
+        HIPCHK(a, hipMemcpyAsync((double*)b->x_rreq.p + (size_t)b->x_roff[(size_t)r] * 4, (const double*)a->x_req.p + (size_t)a->x_soff[(size_t)p] * 4,
+                                 (size_t)a->x_send[(size_t)p] * 32, hipMemcpyDeviceToDevice, a->stream));
+      }
+    { int e = all_sync(); if (e) return e; }
+    for (int r = 0; r < g; ++r) { ctxs[r]->sync = 0; int e = xc_answer(ctxs[r], A[(size_t)r]); if (e) return e; }
+    { int e = all_sync(); if (e) return e; }
+    for (int r = 0; r < g; ++r)                                               // answers, back the same way
+      for (int p = 0; p < g; ++p) {
+        pt_ctx *a = ctxs[r], *b = ctxs[p];                                    // a answered b's requests
+        if (p == r || !a->x_recv[(size_t)p]) continue;
+        const size_t ro = (size_t)a->x_roff[(size_t)p] * k, cnt = (size_t)a->x_recv[(size_t)p] * k, so = (size_t)b->x_soff[(size_t)r] * k;
+        HIPCHK(a, hipMemcpyAsync((uint32_t*)b->x_back_i.p + so, (const uint32_t*)a->x_ans_i.p + ro, cnt * 4, hipMemcpyDeviceToDevice, a->stream));
+        HIPCHK(a, hipMemcpyAsync((double*)b->x_back_d.p + so, (const double*)a->x_ans_d.p + ro, cnt * 8, hipMemcpyDeviceToDevice, a->stream));
+      }
+    { int e = all_sync(); if (e) return e; }
+    for (int r = 0; r < g; ++r) { int e = xd_merge(ctxs[r], A[(size_t)r], blend_mode, rgb_dev ? rgb_dev[r] : nullptr, nrm_dev ? nrm_dev[r] : nullptr); if (e) return e; }
+    return all_sync();
+  };
+  const int e = body();
+  restore();
+  return e;
 }
 
 // ---- texture bake (pt_bake.hip) ------------------------------------------------------------------------------------

@@ -207,6 +207,15 @@ __global__ __launch_bounds__(WG) void blend_list_kernel(const uint32_t* __restri
   blend_one(idx, d2, tgt[list[i]].id, k, mode, attr, n_attr, rgb_out, nrm_out);
 }
 
+// the same for a list of ROW ids (the rows a slab exchange completed with foreign candidates)
+__global__ __launch_bounds__(WG) void blend_rows_kernel(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ rows_n, const uint32_t* __restrict__ idx,
+                                                        const double* __restrict__ d2, int k, int mode, const Attr* __restrict__ attr, uint32_t n_attr,
+                                                        float* __restrict__ rgb_out, float* __restrict__ nrm_out) {
+  const uint32_t i = blockIdx.x * WG + threadIdx.x;
+  if (i >= *rows_n) return;
+  blend_one(idx, d2, rows[i], k, mode, attr, n_attr, rgb_out, nrm_out);
+}
+
 // cyclic Jacobi on a symmetric 3x3 (fp64), same sweep order as the oracle
 __device__ inline void jacobi3(double (&a)[3][3], double (&v)[3][3]) {
 #pragma unroll
@@ -358,6 +367,11 @@ void pt_launch_aos_split(const void* aos, uint32_t n, double* x, double* y, doub
 void pt_launch_pack_attr(const uint8_t* rgb, const float* nrm, uint32_t n, Attr* attr, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(pack_attr_kernel, grid_for(n), dim3(WG), 0, s, rgb, nrm, n, attr);
+}
+void pt_launch_blend_rows(const uint32_t* rows, const uint32_t* rows_n, uint32_t m_max, const uint32_t* idx, const double* d2, int k, int mode,
+                          const Attr* attr, uint32_t n_attr, float* rgb_out, float* nrm_out, hipStream_t s) {
+  if (!m_max) return;
+  hipLaunchKernelGGL(blend_rows_kernel, grid_for(m_max), dim3(WG), 0, s, rows, rows_n, idx, d2, k, mode, attr, n_attr, rgb_out, nrm_out);
 }
 void pt_launch_blend(const uint32_t* idx, const double* d2, uint32_t m, int k, int mode, const Attr* attr, uint32_t n_attr, float* rgb_out,
                      float* nrm_out, hipStream_t s) {

@@ -114,3 +114,18 @@ void pt_launch_bake_faces(const T* sx, const T* sy, const T* sz, const Attr* att
 void pt_launch_bake_resolve(const unsigned long long* keys, uint32_t* bgra, size_t npix, hipStream_t s);
 // edge padding (reference :593-611): out = tex + (dilate(tex, ksize x ksize) & ~alpha), saturating; tmp: R*R words of scratch
 void pt_launch_dilate_pad(const uint32_t* tex, uint32_t* tmp, uint32_t* out, int R, int ksize, hipStream_t s);
+
+// ---- pt_exchange.hip ------------------------------------------------------------------------------
+// requests of the targets that need another slab: fill = false counts them per destination slab (counts[g], zeroed by the caller),
+// fill = true writes packets {x, y, z, k-th d2} at off[s] + cursor[s]++ (cursor zeroed by the caller) and the row they came from
+template <class T>
+void pt_launch_xreq(bool fill, const T* x, const T* y, const T* z, const double* d2, uint32_t m, int k, int axis, const double* bounds_dev, int g, int me,
+                    uint32_t* counts, const uint32_t* off, uint32_t* cursor, double* req, uint32_t* req_row, hipStream_t s);
+template <class T>
+void pt_launch_xunpack(const double* rreq, uint32_t r, T* xyz_planar, double* bound, hipStream_t s);
+// merge bucket answers (bi, bd)[cnt][k] into rows[e]'s lists in place; flags[row] = 1 for every row touched
+void pt_launch_xmerge(const uint32_t* rows, uint32_t cnt, const uint32_t* bi, const double* bd, int k, uint32_t* idx, double* d2, uint8_t* flags, hipStream_t s);
+void pt_launch_xflag_rows(const uint8_t* flags, uint32_t m, uint32_t* rows, uint32_t* count, hipStream_t s);
+// blend of the listed rows (row ids, not sorted positions) from their idx / d2 lists
+void pt_launch_blend_rows(const uint32_t* rows, const uint32_t* rows_n, uint32_t m_max, const uint32_t* idx, const double* d2, int k, int mode,
+                          const Attr* attr, uint32_t n_attr, float* rgb_out, float* nrm_out, hipStream_t s);

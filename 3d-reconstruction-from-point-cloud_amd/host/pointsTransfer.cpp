@@ -18,6 +18,7 @@
 //   --pad K          edge-padding kernel, default 25 (0 = none)
 //   --neighbors FILE also dump the neighbour indices (binary u32[M][K])
 //   --ply-threads T  parser threads for the two input files (default 0 = one per hardware thread; host/ply_fast.h)
+//   --gpus N         the cloud cut into N spatial slabs, one process per GPU, slab exchange over RCCL (host/sharded.h)
 // There is no CPU path: without a usable GPU the tool reports the error and exits non-zero.
 #include <chrono>
 #include <cstdio>
@@ -35,6 +36,7 @@
 #include "ply_fast.h"
 #include "png_write.h"
 #include "pt_api.h"
+#include "sharded.h"
 
 namespace {
 using clk = std::chrono::steady_clock;
@@ -52,6 +54,46 @@ void mem_mib(long& virt, long& res) {   // replaces CGAL::Memory_sizer (referenc
     std::fclose(f);
   }
 }
+// the mesh with the transferred per-vertex colour / normal.  Formatted in parallel (one chunk of records per thread, "%.9g" = what
+// operator<< prints at precision 9), written in order.
+void write_transfer_ply(const std::string& out_name, const ply::FastMesh& mesh, const std::vector<float>& rgb, const std::vector<float>& nrm) {
+  const size_t M = mesh.vertices.size();
+  std::ofstream o(out_name, std::ios::binary);
+  o << "ply\nformat ascii 1.0\nelement vertex " << M << "\n"
+    << "property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+    << "property float s\nproperty float t\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
+    << "element face " << mesh.faces.size() / 3 << "\nproperty list uchar int vertex_indices\nend_header\n";
+  const size_t F = mesh.faces.size() / 3;
+  int nth = (int)std::thread::hardware_concurrency();
+  nth = std::max(1, std::min(nth, 64));
+  nth = (int)std::min<size_t>((size_t)nth, (M + F) / 20000 + 1);
+  std::vector<std::string> part((size_t)nth * 2);
+  auto format = [&](int t) {
+    char buf[256];
+    std::string& sv = part[(size_t)t];
+    const size_t v0 = M * (size_t)t / (size_t)nth, v1 = M * (size_t)(t + 1) / (size_t)nth;
+    sv.reserve((v1 - v0) * 96);
+    for (size_t i = v0; i < v1; ++i) {
+      const Point& v = mesh.vertices[i];
+      const int len = std::snprintf(buf, sizeof buf, "%.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %d %d %d\n", v.x(), v.y(), v.z(), (double)nrm[3 * i],
+                                    (double)nrm[3 * i + 1], (double)nrm[3 * i + 2], v.u(), v.v(), (int)rgb[3 * i], (int)rgb[3 * i + 1],
+                                    (int)rgb[3 * i + 2]);   // float -> uchar truncates, as :100-102
+      sv.append(buf, (size_t)len);
+    }
+    std::string& sf = part[(size_t)nth + (size_t)t];
+    const size_t f0 = F * (size_t)t / (size_t)nth, f1 = F * (size_t)(t + 1) / (size_t)nth;
+    sf.reserve((f1 - f0) * 28);
+    for (size_t f = f0; f < f1; ++f) {
+      const int len = std::snprintf(buf, sizeof buf, "3 %d %d %d\n", mesh.faces[3 * f], mesh.faces[3 * f + 1], mesh.faces[3 * f + 2]);
+      sf.append(buf, (size_t)len);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nth; ++t) th.emplace_back(format, t);
+  format(0);
+  for (auto& t : th) t.join();
+  for (const std::string& sp : part) o.write(sp.data(), (std::streamsize)sp.size());
+}
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -63,8 +105,13 @@ int main(int argc, char** argv) {
   const std::string pc_file_name = argv[1], mesh_file_name = argv[2];
   int K = 20, device = 0, mode = PT_BLEND_MEAN, ply_threads = 0, resolution = 8192, pad = 25;     // K, RESOLUTION: reference :128-129; 25: :594
   std::string out_name = "transfer.ply", nbr_name, tex_name = "texture.png";                      // texture.png: reference :615
+  int gpus = 0, rank = -1;
+  bool finalize = false;
+  std::string rendezvous;
+  std::vector<std::string> passthrough;            // the options a launcher hands to its rank / finalize processes
   for (int i = 3; i < argc; ++i) {
     const std::string a = argv[i];
+    const int i_before = i;
     auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
     if (a == "--k") K = std::atoi(val());
     else if (a == "--device") device = std::atoi(val());
@@ -73,12 +120,37 @@ int main(int argc, char** argv) {
     else if (a == "--texture") tex_name = val();
     else if (a == "--resolution") resolution = std::atoi(val());
     else if (a == "--pad") pad = std::atoi(val());
+    else if (a == "--gpus") { gpus = std::atoi(val()); continue; }                 // (not handed on: the launcher adds it itself)
+    else if (a == "--rank") { rank = std::atoi(val()); continue; }
+    else if (a == "--rendezvous") { rendezvous = val(); continue; }
+    else if (a == "--finalize") { finalize = true; continue; }
     else if (a == "--ply-threads") ply_threads = std::max(0, std::atoi(val()));
     else if (a == "--blend") mode = std::string(val()) == "invd2" ? PT_BLEND_INV_D2 : PT_BLEND_MEAN;
     else { std::cerr << "unknown option " << a << std::endl; return 2; }
+    for (int j = i_before; j <= i; ++j) passthrough.push_back(argv[j]);
   }
   if (K < 1 || K > PT_MAX_K) { std::cerr << "--k must be in [1, " << PT_MAX_K << "]" << std::endl; return 2; }
   if (resolution < 1 || resolution > 32768 || pad < 0 || pad > 255 || (pad > 0 && !(pad & 1))) { std::cerr << "--resolution must be in [1, 32768], --pad 0 or odd" << std::endl; return 2; }
+  if (gpus != 0 || rank >= 0 || finalize) {
+    // the sharded path (host/sharded.h): launcher -> one rank process per GPU -> finalize
+    if (gpus < 1 || gpus > 64) { std::cerr << "--gpus must be in [1, 64]" << std::endl; return 2; }
+    sharded::Options so;
+    so.cloud = pc_file_name; so.mesh = mesh_file_name; so.out_name = out_name; so.tex_name = tex_name; so.rendezvous = rendezvous;
+    so.K = K; so.device = device; so.mode = mode; so.ply_threads = ply_threads; so.resolution = resolution; so.pad = pad; so.gpus = gpus; so.rank = rank;
+    if (rank >= 0) return rank < gpus && !rendezvous.empty() ? sharded::run_rank(so) : 2;
+    if (finalize) return rendezvous.empty() ? 2 : sharded::run_finalize(so, [&](const ply::FastMesh& m, const std::vector<float>& c, const std::vector<float>& n) { write_transfer_ply(out_name, m, c, n); });
+    const auto t0 = clk::now();
+    char self[4096];
+    const ssize_t sl = readlink("/proc/self/exe", self, sizeof self - 1);        // the rank processes run this very binary
+    const int lrc = sharded::run_launcher(so, sl > 0 ? std::string(self, (size_t)sl) : std::string(argv[0]), passthrough);
+    if (lrc != 0) return lrc;
+    std::cout << "Total real time: " << since(t0) << " seconds" << std::endl;
+    long virt, res;
+    mem_mib(virt, res);
+    std::cout << "VIRT: " << virt << " MiB" << std::endl;
+    std::cout << "RES:  " << res << " MiB" << std::endl;
+    return 0;
+  }
 
   const auto t_total = clk::now();
   auto t_task = clk::now();
@@ -168,44 +240,7 @@ int main(int argc, char** argv) {
     return 1;
   }
 
-  if (!out_name.empty()) {   // output: the mesh with transferred colour/normal.  Formatted in parallel (one chunk of records per thread, "%.9g" =
-      // what operator<< prints at precision 9), written in order.
-    std::ofstream o(out_name, std::ios::binary);
-    o << "ply\nformat ascii 1.0\nelement vertex " << M << "\n"
-      << "property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
-      << "property float s\nproperty float t\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
-      << "element face " << mesh.faces.size() / 3 << "\nproperty list uchar int vertex_indices\nend_header\n";
-    const size_t F = mesh.faces.size() / 3;
-    int nth = (int)std::thread::hardware_concurrency();
-    nth = std::max(1, std::min(nth, 64));
-    nth = (int)std::min<size_t>((size_t)nth, (M + F) / 20000 + 1);
-    std::vector<std::string> part((size_t)nth * 2);
-    auto format = [&](int t) {
-      char buf[256];
-      std::string& sv = part[(size_t)t];
-      const size_t v0 = M * (size_t)t / (size_t)nth, v1 = M * (size_t)(t + 1) / (size_t)nth;
-      sv.reserve((v1 - v0) * 96);
-      for (size_t i = v0; i < v1; ++i) {
-        const Point& v = mesh.vertices[i];
-        const int len = std::snprintf(buf, sizeof buf, "%.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %d %d %d\n", v.x(), v.y(), v.z(), (double)nrm[3 * i],
-                                      (double)nrm[3 * i + 1], (double)nrm[3 * i + 2], v.u(), v.v(), (int)rgb[3 * i], (int)rgb[3 * i + 1],
-                                      (int)rgb[3 * i + 2]);   // float -> uchar truncates, as :100-102
-        sv.append(buf, (size_t)len);
-      }
-      std::string& sf = part[(size_t)nth + (size_t)t];
-      const size_t f0 = F * (size_t)t / (size_t)nth, f1 = F * (size_t)(t + 1) / (size_t)nth;
-      sf.reserve((f1 - f0) * 28);
-      for (size_t f = f0; f < f1; ++f) {
-        const int len = std::snprintf(buf, sizeof buf, "3 %d %d %d\n", mesh.faces[3 * f], mesh.faces[3 * f + 1], mesh.faces[3 * f + 2]);
-        sf.append(buf, (size_t)len);
-      }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nth; ++t) th.emplace_back(format, t);
-    format(0);
-    for (auto& t : th) t.join();
-    for (const std::string& sp : part) o.write(sp.data(), (std::streamsize)sp.size());
-  }
+  if (!out_name.empty()) write_transfer_ply(out_name, mesh, rgb, nrm);
   if (!nbr_name.empty()) {
     std::ofstream o(nbr_name, std::ios::binary);
     o.write(reinterpret_cast<const char*>(idx.data()), (std::streamsize)(idx.size() * sizeof(uint32_t)));

@@ -240,6 +240,47 @@ class PointsTransfer:
         self._adopt_torch_stream()
         self._chk(self._L.pt_pca_normals_dev(self._h, _ptr(idx_dev), m, k, _ptr(nrm_out_dev)))
 
+    # -- native slab exchange over RCCL ---------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes every rank needs for comm_init (create on one rank, share out of band -- e.g. a torch.distributed broadcast)."""
+        buf = C.create_string_buffer(128)
+        rc = capi.lib().pt_comm_unique_id(buf)
+        if rc != capi.OK:
+            raise capi.PtError(rc, "pt_comm_unique_id failed (librccl not loadable?)")
+        return bytes(buf.raw)
+
+    def comm_init(self, world, rank, uid):
+        assert len(uid) == 128
+        self._chk(self._L.pt_comm_init(self._h, world, rank, C.create_string_buffer(bytes(uid), 128)))
+
+    def comm_destroy(self):
+        self._chk(self._L.pt_comm_destroy(self._h))
+
+    def exchange_merge_dev(self, xyz_dev, xyz_type, m, k, axis, bounds, idx_dev, d2_dev, blend_mode=-1, rgb_dev=None, nrm_dev=None):
+        """Complete the home-slab lists idx_dev / d2_dev ([m, k], in place) with the other ranks' candidates over RCCL; returns
+        the exchange counters.  blend_mode >= 0 redoes the blend of the completed rows into rgb_dev / nrm_dev."""
+        self._adopt_torch_stream()
+        b = (C.c_double * len(bounds))(*bounds)
+        st = capi.ExchangeStats()
+        self._chk(self._L.pt_exchange_merge_dev(self._h, _ptr(xyz_dev), xyz_type, m, k, axis, b, _ptr(idx_dev), _ptr(d2_dev), blend_mode,
+                                                _ptr(rgb_dev), _ptr(nrm_dev), C.byref(st)))
+        return {f[0]: getattr(st, f[0]) for f in st._fields_}
+
+    @staticmethod
+    def exchange_merge_local(pts, xyz_devs, xyz_type, k, axis, bounds, idx_devs, d2_devs, blend_mode=-1, rgb_devs=None, nrm_devs=None):
+        """The same protocol for G contexts of this process (G logical slabs on one GPU), device copies as the transport."""
+        g = len(pts)
+        for p_ in pts:
+            p_._adopt_torch_stream()
+        arr = lambda items: (C.c_void_p * g)(*[_ptr(t) for t in items])
+        ms = (C.c_uint64 * g)(*[int(x.shape[1]) for x in xyz_devs])
+        b = (C.c_double * len(bounds))(*bounds)
+        rc = capi.lib().pt_exchange_merge_local((C.c_void_p * g)(*[p_._h for p_ in pts]), g, arr(xyz_devs), xyz_type, ms, k, axis, b, arr(idx_devs), arr(d2_devs),
+                                                blend_mode, arr(rgb_devs) if rgb_devs else None, arr(nrm_devs) if nrm_devs else None)
+        if rc != capi.OK:
+            raise capi.PtError(rc, "; ".join(capi.lib().pt_last_error(p_._h).decode() for p_ in pts))
+
     # -- out-of-core source (README.md:3 "billions of points") ---------------------------------------
     def stream_query(self, xyz, chunk_points, k=K_REFERENCE, first_id=0, xyz_type=None):
         """k-NN of the RESIDENT targets in a cloud kept in host memory and streamed through the GPU chunk by chunk;

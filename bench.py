@@ -37,9 +37,22 @@ KERNEL_NAMES = ["bbox_reduce", "pass1_histogram", "pass1_scatter", "pass2_histog
                 "target_sort", "knn_query"]
 
 
+def survey_alg_bytes(name, n, m, k, s=12):
+    """SURVEY.md 8(d)'s algorithmic bytes of the phase a kernel belongs to -- the figure `roofline.achieved` / `frac` are
+    quoted on.  Query (k-NN + blend): N*s + M*s + M*k*16 + M*(4k + 24); build: N*(2s + 4), which 8(d) gives for the whole
+    build and which is split here over its data-moving passes in proportion to the bytes each must move."""
+    if name == "knn_query":
+        return n * s + m * s + m * k * 16 + m * (4 * k + 24)
+    share = {"bbox_reduce": 0.0, "pass1_histogram": 12, "pass1_scatter": 28, "pass2_histogram_scan": 2, "pass2_scatter": 32, "finalize_cellsort": 32}
+    if name in share:
+        return n * (2 * s + 4) * share[name] / sum(share.values())
+    return m * (2 * s + 4)            # target_sort: the same formula over the targets
+
+
 def kernel_alg_bytes(name, n, m, k, s=12):
-    """Algorithmic HBM bytes ONE launch of that kernel must move: inputs read once + outputs
-    written once.  s = bytes per xyz (12 for fp32); records are s+4 (xyz + original index)."""
+    """The IMPLEMENTATION's own minimum for one launch of that kernel: inputs read once + outputs
+    written once with the record sizes this build uses.  s = bytes per xyz (12 for fp32); records are s+4 (xyz + original
+    index).  Reported as `impl_bytes_per_launch`, never as the roofline fraction."""
     rec = s + 4
     return {
         "bbox_reduce": n * s,
@@ -55,19 +68,29 @@ def kernel_alg_bytes(name, n, m, k, s=12):
 
 
 PMC_KERNEL = {"bbox_reduce": "bbox_kernel", "pass1_histogram": "hist_chunk_kernel", "pass1_scatter": "scatter_chunk_kernel",
-              "pass2_histogram_scan": "hist_kernel", "pass2_scatter": "scatter_kernel", "finalize_cellsort": "finalize_kernel",
+              "pass2_histogram_scan": "hist_bid_kernel", "pass2_scatter": "scatter_kernel", "finalize_cellsort": "finalize_kernel",
               "knn_query": "knn_tile_kernel"}
 
 
+def pmc_profile(workload, world):
+    """The newest committed PMC traffic summary of this workload (profiles/rNN_*_<workload>_pmc_traffic.json, written by
+    tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950).  Returns (dict, file name) or (None, None)."""
+    import glob
+    if world != 1:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*%s_pmc_traffic.json" % workload.lower())))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return json.load(f), os.path.basename(files[-1])
+
+
 def pmc_traffic(kernel, workload, world):
-    """HBM bytes of one launch of `kernel` from the committed rocprofv3 PMC passes of the same workload
-    (profiles/r01_v9_c4_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE doubled as
-    /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950).  None when no matching profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_v9_c4_pmc_traffic.json")
-    if workload != "C4" or world != 1 or not os.path.exists(path):
+    """HBM bytes of one launch of `kernel` (or of a whole step, "__step__") from that summary; None when there is none."""
+    prof, _ = pmc_profile(workload, world)
+    if prof is None:
         return None
-    with open(path) as f:
-        prof = json.load(f)
     if kernel == "__step__":
         return prof.get("step", {}).get("hbm_bytes")
     rec = prof["kernels"].get(PMC_KERNEL.get(kernel, ""))
@@ -113,6 +136,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: ranks may share one GPU, collectives staged through host memory")
+    ap.add_argument("--exchange", default="native", choices=["native", "torch"],
+                    help="N > 1: native = pt_exchange_merge_dev (RCCL behind the C ABI: one count-matrix all-gather, grouped send/recv); "
+                         "torch = the torch.distributed all-gather protocol of sharding.py (what the gloo CPU tests drive)")
     ap.add_argument("--source-points", dest="n", type=int, default=0, help="override the workload's source count (rehearsals)")
     ap.add_argument("--target-points", dest="m", type=int, default=0, help="override the workload's target count (rehearsals)")
     args = ap.parse_args()
@@ -172,6 +198,11 @@ def main():
     else:
         pt.build_synth(n_total, seed, **gen)
         pt.targets_synth(m_total, seed, **gen)
+    native = world > 1 and args.exchange == "native" and args.backend == "nccl"
+    if native:        # the library's own RCCL communicator: rank 0 creates the id, torch.distributed only carries its 128 bytes
+        uid = [pt.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0, device=dev)
+        pt.comm_init(world, rank, uid[0])
     n_loc, m_loc = pt.num_source, pt.num_targets
     idx = torch.empty((m_loc, k), dtype=torch.int32, device=dev)
     d2 = torch.empty((m_loc, k), dtype=torch.float64, device=dev)
@@ -203,7 +234,10 @@ def main():
         st = pt.stats() if record else None       # HIP-event times of the build + home search, on the stream they ran on
         if world > 1 and record:                   # (the exchange synchronises with the host anyway: its wall time is a fair phase time)
             torch.cuda.synchronize(); tx = time.perf_counter()
-        xs = sharding.exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds, on_changed=reblend)
+        if native:         # count matrix -> owner-to-owner requests -> bounded answers -> merge -> re-blend, all behind the C ABI
+            xs = pt.exchange_merge_dev(xyz, pkg.F32, m_loc, k, axis, bounds, idx, d2, pkg.BLEND_MEAN, rgb, nrm)
+        else:
+            xs = sharding.exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds, on_changed=reblend)
         if world > 1 and record:
             torch.cuda.synchronize(); phase["exchange_merge_reblend"] = phase.get("exchange_merge_reblend", 0.0) + (time.perf_counter() - tx) * 1e3
         if with_pca:
@@ -243,8 +277,10 @@ def main():
         K = args.steps
         kavg = [v / K for v in kms]
         dom = max(range(8), key=lambda i: kavg[i])
-        alg = kernel_alg_bytes(KERNEL_NAMES[dom], n_loc, m_loc, k)
+        alg = survey_alg_bytes(KERNEL_NAMES[dom], n_loc, m_loc, k)          # what frac is quoted on
+        impl = kernel_alg_bytes(KERNEL_NAMES[dom], n_loc, m_loc, k)        # this build's own minimum, for comparison only
         achieved = alg / (kavg[dom] * 1e-3) / 1e9
+        _, pmc_file = pmc_profile(args.workload, world)
         b_alg_job = n_total * 28 + (n_total * 12 + m_total * 12 + m_total * k * 16 + m_total * (4 * k + 24))
         out = {
             "metric": "target points/sec (k=%d detail transfer)" % k,
@@ -255,10 +291,12 @@ def main():
                                    % (args.workload, n_total, m_total, k, dist_name, type_name, seed),
                        "step": "grid build + target binning + k-NN with fused mean blend + slab exchange/merge%s, inputs resident in HBM"
                                % (" + PCA normals" if with_pca else ""),
-                       "parallelism": "slab%d" % world if world > 1 else "single", "backend": args.backend if world > 1 else None},
+                       "parallelism": "slab%d" % world if world > 1 else "single", "backend": args.backend if world > 1 else None,
+                       "exchange": ("native RCCL (pt_exchange_merge_dev)" if native else "torch.distributed all-gather") if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(KERNEL_NAMES[dom], args.workload, world),
-                         "alg_bytes_per_launch": alg, "avg_launch_ms": kavg[dom]},
+                         "traffic_source": pmc_file, "alg_bytes_per_launch": alg, "alg_bytes_formula": "SURVEY.md 8(d)",
+                         "impl_bytes_per_launch": impl, "impl_achieved": impl / (kavg[dom] * 1e-3) / 1e9, "avg_launch_ms": kavg[dom]},
             "job_roofline": {"alg_bytes_per_step": b_alg_job, "achieved": b_alg_job / (ms_per_step * 1e-3) / 1e9 / world, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s per GPU", "frac": b_alg_job / (ms_per_step * 1e-3) / 1e9 / world / HBM_PEAK_GBS,
                              # HBM bytes every kernel of one step actually moved (same PMC passes, summed over the step's dispatches)
@@ -272,6 +310,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if native:
+        pt.comm_destroy()
     pt.close()
     if world > 1:
         dist.barrier()

@@ -203,6 +203,40 @@ int  pt_pack_requests_dev(pt_ctx*, const void* tgt_xyz_dev, int xyz_type, const 
 int  pt_query_bounded_dev(pt_ctx*, const void* xyz_dev, int xyz_type, const double* bound2_dev, uint64_t m,
                           int k, uint32_t* idx_dev, double* d2_dev);
 
+/* ---- native slab exchange: RCCL over xGMI behind the C ABI, one rank per process and GPU ---------------
+ * After every rank has searched its HOME targets in its own slab (pt_query_*), pt_exchange_merge_dev completes the lists:
+ *   1. the targets whose k-th distance reaches another slab (Distance::min_distance_to_rectangle, src/Distance.h:27-57, on
+ *      the slab boxes) are counted per destination; ONE all-gather ships the G x G count matrix (the only host read-back);
+ *   2. grouped ncclSend / ncclRecv carry 32-byte request packets {x, y, z, k-th d2} owner to owner (all links at once);
+ *   3. every rank answers what it received with a radius-bounded search of its slab;
+ *   4. the k candidates per request travel back the same way and are merged under the total order (d2, index);
+ *   5. optionally the rows that were completed get their blend redone (blend_mode >= 0 and rgb / nrm outputs given).
+ * pt_comm_unique_id (any one rank) creates the 128-byte RCCL id the ranks share out of band; pt_comm_init joins the
+ * communicator on the context's device -- call it before the heavy GPU work of the process.  bounds: world + 1 ascending
+ * slab bounds along `axis` (first / last may be -inf / +inf).  librccl is loaded at pt_comm_* time (dlopen), not at link time.
+ * pt_exchange_merge_local runs the same phases for G contexts of ONE process with device copies as transport (G logical
+ * slabs on one GPU: what tests use where only one GPU exists). */
+#define PT_COMM_ID_BYTES 128
+typedef struct pt_exchange_stats_t {
+  uint64_t crossing;        /* request packets this rank sent (a target needing two slabs counts twice) */
+  uint64_t answered;        /* request packets this rank answered */
+  uint64_t bytes_sent, bytes_received;   /* requests + answers, this rank */
+  double ms;                /* device time of the whole exchange on this rank's stream (HIP events) */
+} pt_exchange_stats_t;
+int  pt_comm_unique_id(void* id_out);
+int  pt_comm_init(pt_ctx*, int world, int rank, const void* id);
+int  pt_comm_destroy(pt_ctx*);
+int  pt_exchange_merge_dev(pt_ctx*, const void* tgt_xyz_dev, int xyz_type, uint64_t m, int k, int slab_axis, const double* slab_bounds,
+                           uint32_t* idx_dev, double* d2_dev, int blend_mode, float* rgb_dev, float* nrm_dev, pt_exchange_stats_t* stats_or_null);
+/* One rank's whole query for a C++ host that holds no device memory: the home targets (planar host xyz) are searched in this
+ * rank's slab with the blend fused in, completed by pt_exchange_merge_dev (world > 1), and idx / d2 / rgb / nrm come back to
+ * host memory ([m][k], [m][k], [m][3], [m][3]; rgb / nrm may be NULL, blend_mode < 0 skips the blend). */
+int  pt_query_exchange_blend(pt_ctx*, const void* tgt_xyz, int xyz_type, uint64_t m, int k, int slab_axis, const double* slab_bounds, int blend_mode,
+                             uint32_t* idx_out, double* d2_out, float* rgb_out, float* nrm_out, pt_exchange_stats_t* stats_or_null);
+int  pt_exchange_merge_local(pt_ctx* const* ctxs, int g, const void* const* tgt_xyz_dev, int xyz_type, const uint64_t* m, int k, int slab_axis,
+                             const double* slab_bounds, uint32_t* const* idx_dev, double* const* d2_dev, int blend_mode, float* const* rgb_dev,
+                             float* const* nrm_dev);
+
 /* ---- streamed upload of a planar cloud: what a file reader feeds while it is still parsing ---------
  * Replaces the copy of the points into the tree, `Tree tree(points.begin(), points.end())` (src/pointsTransfer.cpp:259),
  * for callers that hold x[] y[] z[] (+ rgb, normals) instead of 80-byte records: 39 bytes per point cross PCIe instead of 80.

