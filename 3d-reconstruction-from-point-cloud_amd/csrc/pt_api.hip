@@ -585,7 +585,7 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
     const int k = (int)value;
     if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k_hint out of range");
     // (k in 25..32: 8.7 keeps the region inside LDS; ring 1 then fails for ~1 target in 8, which the group kernel finishes)
-    c->rho = k <= 8 ? 4.0 : (k <= 16 ? 6.0 : (k <= 24 ? 8.0 : (k <= PT_TILE_MAX_K ? 8.7 : 12.0)));
+    c->rho = k <= 8 ? 4.0 : (k <= 16 ? 6.0 : (k <= 20 ? 7.0 : (k <= 24 ? 8.0 : (k <= PT_TILE_MAX_K ? 8.7 : 12.0))));   // (k = 20 at 100M / 10M: rho 6 7.2 ms, 7 7.0, 8 7.4)
     return PT_OK;
   }
   if (!strcmp(name, "sync")) { c->sync = value != 0; return PT_OK; }

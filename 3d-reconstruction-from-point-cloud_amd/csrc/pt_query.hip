@@ -501,7 +501,10 @@ struct TileBlocks { const uint32_t* blocks; uint32_t* retry; uint32_t* retry_n; 
 // error of a source point (2^-24 * largest |coordinate| of the cloud's bounding box).
 struct TileDouble { const RecD* src; const RecD* tgt; float e_src; };
 
-template <int K, int TILE_CAP, int TWG, bool WIDE = false, bool BLEND = false, bool DBL = false>
+// KC: length of pass 1's per-lane value chain (<= K).  The merges and the ranking run at width K (a power of two); a chain of KC
+// entries leaves l32[KC..K) at +inf, which is all a query with k <= KC needs: the reference's K = 20 runs the K = 32 body with
+// a 24-deep chain (three quarters of pass 1's per-candidate work).
+template <int K, int TILE_CAP, int TWG, bool WIDE = false, bool BLEND = false, bool DBL = false, int KC = K>
 __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(GridParams gp, const RecF* __restrict__ src, const uint32_t* __restrict__ cs,
                                                         const RecF* __restrict__ tgt, const uint32_t* __restrict__ tblock_start, int k,
                                                         uint32_t* __restrict__ out_idx, double* __restrict__ out_d2,
@@ -530,7 +533,18 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
   const int bx = (int)(macro % (uint32_t)gp.mdim[0]) * 8 + (int)((m9 & 1u) | ((m9 >> 2) & 2u) | ((m9 >> 4) & 4u));
   const int by = (int)((macro / (uint32_t)gp.mdim[0]) % (uint32_t)gp.mdim[1]) * 8 + (int)(((m9 >> 1) & 1u) | ((m9 >> 3) & 2u) | ((m9 >> 5) & 4u));
   const int bz = (int)(macro / (uint32_t)(gp.mdim[0] * gp.mdim[1])) * 8 + (int)(((m9 >> 2) & 1u) | ((m9 >> 4) & 2u) | ((m9 >> 6) & 4u));
+#if defined(PT_ABLATE) && PT_ABLATE == 4
+  // timing-only build: every workgroup stages the region of one of 512 HOT blocks (one macro block in the middle of the grid:
+  // L2 / Infinity-Cache resident) and its targets are shifted into that block -- same ranking work, no HBM traffic for staging
+  const uint32_t hmacro = (uint32_t)(((gp.mdim[2] / 2) * gp.mdim[1] + gp.mdim[1] / 2) * gp.mdim[0] + gp.mdim[0] / 2), hm9 = b & 511u;
+  const int hbx = (int)(hmacro % (uint32_t)gp.mdim[0]) * 8 + (int)((hm9 & 1u) | ((hm9 >> 2) & 2u) | ((hm9 >> 4) & 4u));
+  const int hby = (int)((hmacro / (uint32_t)gp.mdim[0]) % (uint32_t)gp.mdim[1]) * 8 + (int)(((hm9 >> 1) & 1u) | ((hm9 >> 3) & 2u) | ((hm9 >> 5) & 4u));
+  const int hbz = (int)(hmacro / (uint32_t)(gp.mdim[0] * gp.mdim[1])) * 8 + (int)(((hm9 >> 2) & 1u) | ((hm9 >> 4) & 2u) | ((hm9 >> 6) & 4u));
+  const double hshift[3] = {(double)((hbx - bx) * 8) * gp.h, (double)((hby - by) * 8) * gp.h, (double)((hbz - bz) * 8) * gp.h};
+  const int ox = hbx * 8 - 1, oy = hby * 8 - 1, oz = hbz * 8 - 1;
+#else
   const int ox = bx * 8 - 1, oy = by * 8 - 1, oz = bz * 8 - 1;          // cell coordinates of region cell (0,0,0)
+#endif
 
   // ---- A: region cell table (global start + LDS offset of each of the 1000 cells).  One thread per region ROW (y, z):
   //         cells x = 1..8 of a row are eight consecutive keys of one block, so a row needs three key computations
@@ -680,6 +694,9 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
       if (active) { const RecD td = dd.tgt[t]; q[0] = td.x; q[1] = td.y; q[2] = td.z; tr.x = (float)td.x; tr.y = (float)td.y; tr.z = (float)td.z; tr.id = td.id; }
     } else {
       if (active) tr = tgt[t];
+#if defined(PT_ABLATE) && PT_ABLATE == 4
+      tr.x = (float)((double)tr.x + hshift[0]); tr.y = (float)((double)tr.y + hshift[1]); tr.z = (float)((double)tr.z + hshift[2]);
+#endif
       q[0] = (double)tr.x; q[1] = (double)tr.y; q[2] = (double)tr.z;
     }
     double u[3];
@@ -708,7 +725,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
       float prev = l32[0];
       l32[0] = fminf(x, prev);
 #pragma unroll
-      for (int j = 1; j < K; ++j) { const float cur = l32[j]; l32[j] = __builtin_amdgcn_fmed3f(x, prev, cur); prev = cur; }
+      for (int j = 1; j < KC; ++j) { const float cur = l32[j]; l32[j] = __builtin_amdgcn_fmed3f(x, prev, cur); prev = cur; }
     };
     {
       uint32_t ps[4], pe[4];
@@ -849,7 +866,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
         }
       }
     };
-    if constexpr (K > 16) {                           // (register budget: one ranking body only)
+    if constexpr (K > 16 && WIDE) {                   // (the wide variant's register budget: one ranking body only)
       rank_all([](double ad, uint32_t ai, double bd, uint32_t bi) { return key_lt(ad, ai, bd, bi); });
     } else {
       rank_all([](double ad, uint32_t, double bd, uint32_t) { return ad < bd; });
@@ -1068,19 +1085,20 @@ void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* c
   const TileBlend bl{attr, n_attr, mode, rgb_out, nrm_out};
   const TileBlocks tbk{blocks, retry, retry_n, (uint32_t)PT_TILE_CAP_LARGE};
   const TileDouble dd{src_exact, tgt_exact, e_src};
-#define PT_TILE_LAUNCH1(KK, CAP, TH, WD, BL, DB)                                                                                              \
-  hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH, WD, BL, DB>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, \
+#define PT_TILE_LAUNCH1(KK, CAP, TH, WD, BL, DB, KCH)                                                                                             \
+  hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH, WD, BL, DB, KCH>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, \
                      out_d2, todo, todo_n, bl, tbk, dd)
-#define PT_TILE_LAUNCH(KK, CAP, TH, WD)                                   \
+#define PT_TILE_LAUNCHC(KK, CAP, TH, WD, KCH)                             \
   do {                                                                    \
     if (src_exact) {                                                      \
-      if (attr) PT_TILE_LAUNCH1(KK, CAP, TH, WD, true, true);             \
-      else PT_TILE_LAUNCH1(KK, CAP, TH, WD, false, true);                 \
+      if (attr) PT_TILE_LAUNCH1(KK, CAP, TH, WD, true, true, KCH);        \
+      else PT_TILE_LAUNCH1(KK, CAP, TH, WD, false, true, KCH);            \
     } else {                                                              \
-      if (attr) PT_TILE_LAUNCH1(KK, CAP, TH, WD, true, false);            \
-      else PT_TILE_LAUNCH1(KK, CAP, TH, WD, false, false);                \
+      if (attr) PT_TILE_LAUNCH1(KK, CAP, TH, WD, true, false, KCH);       \
+      else PT_TILE_LAUNCH1(KK, CAP, TH, WD, false, false, KCH);           \
     }                                                                     \
   } while (0)
+#define PT_TILE_LAUNCH(KK, CAP, TH, WD) PT_TILE_LAUNCHC(KK, CAP, TH, WD, KK)
   const int small = geometry == 1;
   if (k > 24) PT_TILE_LAUNCH(32, PT_TILE_CAP_WIDE, 512, true);      // wide queue, 512 threads, one workgroup per CU
   else if (small && k <= 16) {       // (K = 32 needs more registers than two workgroups per CU leave: large geometry only)
@@ -1089,9 +1107,11 @@ void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* c
   } else {
     if (k <= 8) PT_TILE_LAUNCH(8, PT_TILE_CAP_LARGE, 768, false);
     else if (k <= 16) PT_TILE_LAUNCH(16, PT_TILE_CAP_LARGE, 768, false);
+    else if (k <= 24) PT_TILE_LAUNCHC(32, PT_TILE_CAP_LARGE, 768, false, 24);       // the reference's K = 20 (src/pointsTransfer.cpp:128)
     else PT_TILE_LAUNCH(32, PT_TILE_CAP_LARGE, 768, false);
   }
 #undef PT_TILE_LAUNCH
+#undef PT_TILE_LAUNCHC
 #undef PT_TILE_LAUNCH1
 }
 
