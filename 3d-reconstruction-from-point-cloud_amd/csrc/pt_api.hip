@@ -66,6 +66,12 @@ struct pt_ctx {
   DevBuf t_xyz, t_gidx, trec, trec_tmp;
   DevBuf x_xyz;                // transient targets of pt_query_soa / _aos / _bounded_dev (resident targets stay untouched)
   bool t_has_gidx = false;
+  // refinement of heavy cells (pt_refine.hip): sub-grids inside cells with more than refine_threshold points
+  double refine_threshold = 2048.0;     // 0: never refine.  Measured on the clustered generator (tools/probe_clustered.py): descending into a
+                                        // sub-grid beats scanning the cell end to end from a few thousand points up -- 1B / 50M / k = 32: 3.16 s
+                                        // unrefined, 2.23 s at 512, 2.12 s at 2048; 100M / 5M / k = 8: 34.1 / 42.1 / 35.8 / 37.7 ms at 0 / 512 / 2048 / 8192
+  DevBuf cell_node, nodes;
+  uint32_t n_nodes = 0, refine_levels = 0;
   // slab exchange (pt_comm_* / pt_exchange_*)
   void* nccl_comm = nullptr;
   hipEvent_t xev[2] = {nullptr, nullptr};                     // exchange timing (run_query uses ev[0..2] itself)
@@ -252,6 +258,7 @@ int rebuild(pt_ctx* c) {
   uint32_t nblocks = 0;
   size_t ncells = 0;
   c->st.n_refine = 0;
+  uint32_t max_cell = 0;            // points of the fullest cell of the final grid (adaptive builds)
   for (int iter = 0;; ++iter) {
     choose_grid(c, mn, mx, force_h);
     if (guessed && iter == 0) {           // widen the sampled box into the grid's own padding; no room on some axis: no guess
@@ -308,11 +315,12 @@ int rebuild(pt_ctx* c) {
     }
     c->st.rho_occupied = 0.0;
     if (!c->adaptive || !c->n) break;
-    HIPCHK(c, hipMemsetAsync(occ, 0, 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(occ, 0, 8, c->stream));
     pt_launch_sum_u32(c->stb.block_count, nblocks, occ, c->stream);
-    HIPCHK(c, hipMemcpyAsync(c->h_counter + 8, occ, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_counter + 8, occ, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const double occupied = std::max<double>(1.0, c->h_counter[8]);
+    max_cell = c->h_counter[9];
     c->st.rho_occupied = (double)c->n / occupied;
     if (iter >= 3 || c->st.rho_occupied <= 1.5 * c->rho) break;
     const double h_old = c->gp.h;
@@ -326,6 +334,38 @@ int rebuild(pt_ctx* c) {
     if (!changed || !finer) break;                 // already at the resolution limit (or nothing left to split)
     ++c->st.n_refine;
   }
+  // ---- heavy cells get sub-grids (pt_refine.hip): only clouds whose fullest cell is over the threshold pay anything here ----
+  c->n_nodes = 0; c->refine_levels = 0;
+  if (c->refine_threshold >= 1.0 && c->adaptive && c->n && (double)max_cell > c->refine_threshold) {
+    const uint32_t thr = (uint32_t)c->refine_threshold;
+    // every node holds more than thr points of its level, and the levels nest: at most n / thr nodes per level
+    const uint64_t cap64 = std::min<uint64_t>((uint64_t)PT_REFINE_DEPTH * (c->n / thr + 1) + 16, 0x7FFFFFF0ull / PT_NODE_WORDS * 8);
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(cap64, 64u << 20);
+    RES(c, c->cell_node, (ncells + 1) * sizeof(uint32_t));
+    RES(c, c->nodes, (size_t)cap * PT_NODE_WORDS * sizeof(uint32_t));
+    uint32_t* cnt = (uint32_t*)c->counter.p + 10;
+    HIPCHK(c, hipMemsetAsync(cnt, 0, 4, c->stream));
+    pt_launch_heavy_cells(c->gp, (const uint32_t*)c->cell_start.p, (uint32_t)ncells, thr, (uint32_t*)c->cell_node.p, cnt, cap, (uint32_t*)c->nodes.p, c->stream);
+    uint32_t n0 = 0, n1 = 0;
+    for (int level = 0; level < PT_REFINE_DEPTH; ++level) {
+      HIPCHK(c, hipMemcpyAsync(c->h_counter + 10, cnt, 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));                       // one read-back per level: how many nodes the level has
+      n1 = std::min(c->h_counter[10], cap);
+      HIPCHK(c, hipMemcpyAsync(cnt, &n1, 4, hipMemcpyHostToDevice, c->stream));      // (a counter that ran past the capacity is put back)
+      if (n1 == n0) break;
+      if (c->src_type == PT_F32) pt_launch_refine_nodes<RecF>(c->gp, (RecF*)c->rec.p, (RecF*)c->rec_tmp.p, n0, n1, (uint32_t*)c->nodes.p, c->stream);
+      else pt_launch_refine_nodes<RecD>(c->gp, (RecD*)c->rec.p, (RecD*)c->rec_tmp.p, n0, n1, (uint32_t*)c->nodes.p, c->stream);
+      const bool last = level + 1 == PT_REFINE_DEPTH;
+      pt_launch_heavy_subcells(n0, n1, last ? 0xFFFFFFFFu : thr, cnt, cap, (uint32_t*)c->nodes.p, c->stream);
+      c->refine_levels = (uint32_t)level + 1;
+      n0 = n1;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));                         // (n1 above is host memory the last copy reads)
+    c->n_nodes = n1;
+    if (c->src_type == PT_F64 && c->stb.shadow32 && n1) pt_launch_reshadow((const RecD*)c->rec.p, (uint32_t)c->n, c->stb.shadow32, c->stream);
+    HIPCHK(c, hipGetLastError());
+  }
+  c->st.n_nodes = c->n_nodes; c->st.refine_levels = (int32_t)c->refine_levels; c->st.max_cell_points = max_cell;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   HIPCHK(c, hipGetLastError());
   if (c->src_type == PT_F64 && c->stb.shadow32) {
@@ -427,6 +467,17 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     return PT_OK;
   };
   uint32_t* todo_n = (uint32_t*)c->counter.p + 4;
+  // what the tile kernel does not take (or leaves over) goes to the 8-lanes-per-target kernel: the plain one, or -- when the build
+  // refined heavy cells -- the one that descends into their sub-grids instead of scanning them end to end
+  const bool hier = c->n_nodes > 0;
+  auto group_f32 = [&](const RecF* tg, const double* bnd, const uint32_t* list, const uint32_t* list_n) {
+    if (hier) pt_launch_knn_hier<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const uint32_t*)c->cell_node.p, (const uint32_t*)c->nodes.p, (uint32_t)c->refine_threshold, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream);
+    else pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream);
+  };
+  auto group_f64 = [&](const RecD* tg, const double* bnd, const uint32_t* list, const uint32_t* list_n) {
+    if (hier) pt_launch_knn_hier<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, (const uint32_t*)c->cell_node.p, (const uint32_t*)c->nodes.p, (uint32_t)c->refine_threshold, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream);
+    else pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream);
+  };
   if (ttype == PT_F32) {
     const float* x = (const float*)txyz;
     // targets only need to be grouped by block (tile kernel) -- the cell-level pass is skipped
@@ -435,15 +486,13 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (use_tile) {
       { int r = tile_launches((const RecF*)c->rec.p, tsorted, nullptr, nullptr, todo_n); if (r != PT_OK) return r; }
-      pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, nullptr, idx_dev, d2_dev,
-                          (const uint32_t*)c->todo.p, todo_n, c->stream);
+      group_f32(tsorted, nullptr, (const uint32_t*)c->todo.p, todo_n);
       if (br)   // the targets the tile kernel handed over get their blend from the lists the group kernel just wrote
         pt_launch_blend_list<RecF>((const uint32_t*)c->todo.p, todo_n, m, tsorted, idx_dev, d2_dev, k, br->mode, (const Attr*)c->attr.p,
                                    (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
       HIPCHK(c, hipMemcpyAsync(c->h_counter + 4, todo_n, 4, hipMemcpyDeviceToHost, c->stream));
     } else {
-      pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, bound2_dev, idx_dev, d2_dev,
-                          nullptr, nullptr, c->stream);
+      group_f32(tsorted, bound2_dev, nullptr, nullptr);
       if (br) pt_launch_blend(idx_dev, d2_dev, m, k, br->mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
     }
   } else {
@@ -453,15 +502,13 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (use_tile) {
       { int r = tile_launches((const RecF*)c->rec32.p, nullptr, (const RecD*)c->rec.p, tsorted, todo_n); if (r != PT_OK) return r; }
-      pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, nullptr, idx_dev, d2_dev,
-                          (const uint32_t*)c->todo.p, todo_n, c->stream);
+      group_f64(tsorted, nullptr, (const uint32_t*)c->todo.p, todo_n);
       if (br)
         pt_launch_blend_list<RecD>((const uint32_t*)c->todo.p, todo_n, m, tsorted, idx_dev, d2_dev, k, br->mode, (const Attr*)c->attr.p,
                                    (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
       HIPCHK(c, hipMemcpyAsync(c->h_counter + 4, todo_n, 4, hipMemcpyDeviceToHost, c->stream));
     } else {
-      pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, tsorted, m, k, bound2_dev, idx_dev, d2_dev,
-                          nullptr, nullptr, c->stream);
+      group_f64(tsorted, bound2_dev, nullptr, nullptr);
       if (br) pt_launch_blend(idx_dev, d2_dev, m, k, br->mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
     }
   }
@@ -557,7 +604,7 @@ void pt_ctx_destroy(pt_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in_xyz, &c->in_gidx, &c->attr, &c->rec, &c->rec_tmp, &c->cell_start, &c->stb_mem, &c->t_xyz, &c->t_gidx, &c->trec,
                    &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr, &c->retry, &c->rec32, &c->up_rgb, &c->up_nrm, &c->x_bounds, &c->x_counts, &c->x_matrix, &c->x_off, &c->x_req, &c->x_row, &c->x_rreq,
-                   &c->x_rxyz, &c->x_rbound, &c->x_ans_i, &c->x_ans_d, &c->x_back_i, &c->x_back_d, &c->x_flags, &c->x_rows};
+                   &c->x_rxyz, &c->x_rbound, &c->x_ans_i, &c->x_ans_d, &c->x_back_i, &c->x_back_d, &c->x_flags, &c->x_rows, &c->cell_node, &c->nodes};
   for (DevBuf* b : all) release(c, *b);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);
@@ -591,6 +638,7 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!strcmp(name, "sync")) { c->sync = value != 0; return PT_OK; }
   if (!strcmp(name, "adaptive")) { c->adaptive = value != 0; return PT_OK; }
   if (!strcmp(name, "tile")) { c->tile = (int)value; return PT_OK; }
+  if (!strcmp(name, "refine_threshold")) { if (!(value >= 0 && value <= 1e9)) return fail(c, PT_ERR_ARG, "refine_threshold out of range"); c->refine_threshold = value; return PT_OK; }
   if (!strcmp(name, "guess_min_points")) { c->guess_min_points = value < 1 ? 1 : (uint64_t)value; return PT_OK; }   // sampled-bbox builds from this size up   // 0 group kernel only, 1 auto, 2 small tiles, 3 large tiles
   if (!strcmp(name, "own_stream")) { if (value != 0) c->stream = c->own_stream; return PT_OK; }
   return fail(c, PT_ERR_ARG, "unknown parameter '%s'", name);

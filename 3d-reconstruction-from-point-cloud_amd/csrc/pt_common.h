@@ -22,6 +22,13 @@
 #define PT_CELL_EPS 1e-9            // slack (in cell units) on every cell-box bound: cell membership is
                                     // computed in fp64 with ~1e-12 cell units of rounding at most
 
+// refined ("heavy") cells, pt_refine.hip: one node = header {origin x, y, z in level-0 cell units, sub-cells per cell unit} as four
+// doubles, 513 absolute starts of its 8 x 8 x 8 sub-cells (sub = sz << 6 | sy << 3 | sx), 512 child node ids (id + 1, 0 = leaf)
+#define PT_NODE_START 8
+#define PT_NODE_CHILD (PT_NODE_START + 513)
+#define PT_NODE_WORDS 1040
+#define PT_REFINE_DEPTH 3           // levels below the grid: sub-cells of 1/8, 1/64, 1/512 of a cell side
+
 struct RecF { float x, y, z; uint32_t id; };                     // 16 B
 struct RecD { double x, y, z; uint32_t id; uint32_t pad; };      // 32 B
 struct Attr { uint32_t rgba; float nx, ny, nz; };                // 16 B
@@ -56,6 +63,14 @@ __host__ __device__ inline uint32_t pt_morton9(uint32_t bx, uint32_t by, uint32_
 __host__ __device__ inline uint32_t pt_block_id(const int* mdim, int cx, int cy, int cz) {
   const uint32_t macro = ((uint32_t)(cz >> 6) * (uint32_t)mdim[1] + (uint32_t)(cy >> 6)) * (uint32_t)mdim[0] + (uint32_t)(cx >> 6);
   return (macro << 9) | pt_morton9((uint32_t)(cx >> 3) & 7u, (uint32_t)(cy >> 3) & 7u, (uint32_t)(cz >> 3) & 7u);
+}
+// cell key -> cell coordinates (inverse of pt_block_id << 9 | pt_local_cell)
+__host__ __device__ inline void pt_decode_cell(const GridParams& gp, uint32_t key, int& cx, int& cy, int& cz) {
+  const uint32_t blk = key >> 9, local = key & 511u, macro = blk >> 9, m9 = blk & 511u;
+  const int bx = (int)(macro % (uint32_t)gp.mdim[0]) * 8 + (int)((m9 & 1u) | ((m9 >> 2) & 2u) | ((m9 >> 4) & 4u));
+  const int by = (int)((macro / (uint32_t)gp.mdim[0]) % (uint32_t)gp.mdim[1]) * 8 + (int)(((m9 >> 1) & 1u) | ((m9 >> 3) & 2u) | ((m9 >> 5) & 4u));
+  const int bz = (int)(macro / (uint32_t)(gp.mdim[0] * gp.mdim[1])) * 8 + (int)(((m9 >> 2) & 1u) | ((m9 >> 4) & 2u) | ((m9 >> 6) & 4u));
+  cx = bx * 8 + (int)(local & 7u); cy = by * 8 + (int)((local >> 3) & 7u); cz = bz * 8 + (int)(local >> 6);
 }
 __host__ __device__ inline uint32_t pt_local_cell(int cx, int cy, int cz) {
   return (uint32_t)(((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7));

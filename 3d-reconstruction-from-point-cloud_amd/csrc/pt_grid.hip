@@ -514,19 +514,23 @@ __global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ i
   // non-empty cells of this block (the host derives the points per OCCUPIED cell from their sum).  One plain store per
   // block into a table: a single shared atomic counter would serialise ~5e5 workgroups on one address.
   const uint32_t nzw = (uint32_t)__popcll(__ballot(c0 > 0));
+  uint32_t cmax = c0;                          // most populated cell of the wave: what tells the host that cells need refining
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, o));
   const uint32_t incl = wave_incl_scan(c0);
   __shared__ uint32_t wnz[FWG / 64];
+  __shared__ uint32_t wmx[FWG / 64];
   if (lane == 63) wsum[w] = incl;
-  if (lane == 0) wnz[w] = nzw;
+  if (lane == 0) { wnz[w] = nzw; wmx[w] = cmax; }
   __syncthreads();
   uint32_t off = 0;
 #pragma unroll
   for (int i = 0; i < FWG / 64; ++i) if (i < w) off += wsum[i];
   if (occupied && threadIdx.x == 0) {
-    uint32_t nz = 0;
+    uint32_t nz = 0, mx = 0;
 #pragma unroll
-    for (int i = 0; i < FWG / 64; ++i) nz += wnz[i];
-    occupied[b] = nz;
+    for (int i = 0; i < FWG / 64; ++i) { nz += wnz[i]; mx = max(mx, wmx[i]); }
+    occupied[b] = nz | (min(mx, 0x3FFFFFu) << 10);       // non-empty cells (<= 512) | points of the fullest cell, saturated
   }
   const uint32_t ex = off + incl - c0;
   cnt[threadIdx.x] = ex;                      // cursor, relative to s
@@ -571,12 +575,13 @@ __global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ i
   }
 }
 
+// finalize's per-block words {non-empty cells | fullest cell << 10}: out[0] += sum of the former, out[1] = max of the latter
 __global__ __launch_bounds__(WG) void sum_u32_kernel(const uint32_t* __restrict__ v, uint32_t n, uint32_t* out) {
-  uint32_t acc = 0;
-  for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) acc += v[i];
+  uint32_t acc = 0, mx = 0;
+  for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) { const uint32_t w = v[i]; acc += w & 0x3FFu; mx = max(mx, w >> 10); }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+  for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
+  if ((threadIdx.x & 63) == 0) { if (acc) atomicAdd(out, acc); if (mx) atomicMax(out + 1, mx); }
 }
 
 template <class Rec> constexpr int items_for() { return sizeof(Rec) == 16 ? 8 : 4; }

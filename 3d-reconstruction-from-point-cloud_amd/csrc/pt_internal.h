@@ -18,7 +18,7 @@ struct SortTables {
   uint32_t* scan_tmp;    // [>= nblocks/2048 + 2]
   uint32_t* chunk_hist;  // [nchunks][nbins1]   per-chunk pass-1 histograms, then per-chunk bin cursors
   uint32_t* chunk_gsum;  // [ceil(nchunks/64)][nbins1]
-  uint32_t* occupied;    // optional [nblocks]: non-empty cells of every block, written by finalize (may alias block_count)
+  uint32_t* occupied;    // optional [nblocks]: non-empty cells of every block | points of its fullest cell << 10, written by finalize (may alias block_count)
   RecF* shadow32;        // optional [npoints] (fp64 clouds): fp32-rounded copy of the sorted records, id = sorted position (tile kernel's LDS image)
   uint16_t* bid;         // [npoints] (two-level sorts): block-in-macro of every record as pass 1 placed it -- what pass 2's histogram reads
   hipError_t* status;    // optional: receives the first HIP error of the sort's launch path (hipSuccess otherwise)
@@ -40,7 +40,7 @@ template <class T, class Rec>
 const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, const T* z, const uint32_t* gidx, uint32_t n,
                                Rec* out_final, Rec* tmp, uint32_t* cell_start, const SortTables& tb, bool do_finalize, hipStream_t s,
                                uint64_t* bbox6_verify = nullptr);   // two-level sorts: pass 1's histogram also reduces the exact bbox into it
-void pt_launch_sum_u32(const uint32_t* v, uint32_t n, uint32_t* out, hipStream_t s);   // *out += sum(v[0..n))
+void pt_launch_sum_u32(const uint32_t* v, uint32_t n, uint32_t* out, hipStream_t s);   // finalize's block words: out[0] += non-empty cells, out[1] = max(fullest cell)
 int pt_sort_tile_points(size_t rec_size);
 int pt_sort_chunk_tiles(uint32_t n, size_t rec_size);
 uint32_t pt_sort_num_chunks(uint32_t n, size_t rec_size);
@@ -129,3 +129,19 @@ void pt_launch_xflag_rows(const uint8_t* flags, uint32_t m, uint32_t* rows, uint
 // blend of the listed rows (row ids, not sorted positions) from their idx / d2 lists
 void pt_launch_blend_rows(const uint32_t* rows, const uint32_t* rows_n, uint32_t m_max, const uint32_t* idx, const double* d2, int k, int mode,
                           const Attr* attr, uint32_t n_attr, float* rgb_out, float* nrm_out, hipStream_t s);
+
+// ---- pt_refine.hip ------------------------------------------------------------------------------
+// cells with more than `threshold` points become nodes (cell_node[c] = node id + 1, else 0; *node_count counts them, also past node_cap)
+void pt_launch_heavy_cells(const GridParams& gp, const uint32_t* cs, uint32_t ncells, uint32_t threshold, uint32_t* cell_node, uint32_t* node_count,
+                           uint32_t node_cap, uint32_t* nodes, hipStream_t s);
+// the same one level down for the nodes [n0, n1) (their tables must be built); threshold 0xFFFFFFFF just clears the child tables
+void pt_launch_heavy_subcells(uint32_t n0, uint32_t n1, uint32_t threshold, uint32_t* node_count, uint32_t node_cap, uint32_t* nodes, hipStream_t s);
+// counting sort of the records of the nodes [n0, n1) by sub-cell, in place (tmp: scratch of the same size as rec), + their start tables
+template <class Rec>
+void pt_launch_refine_nodes(const GridParams& gp, Rec* rec, Rec* tmp, uint32_t n0, uint32_t n1, uint32_t* nodes, hipStream_t s);
+void pt_launch_reshadow(const RecD* rec, uint32_t n, RecF* shadow, hipStream_t s);
+// k-NN over the refined grid (group kernel with hierarchical cell scans): same contract as pt_launch_knn
+template <class Rec>
+void pt_launch_knn_hier(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const uint32_t* cell_node, const uint32_t* nodes, uint32_t node_thr,
+                        const Rec* tgt, uint32_t m, int k, const double* bound2, uint32_t* out_idx, double* out_d2, const uint32_t* list,
+                        const uint32_t* list_n, hipStream_t s);

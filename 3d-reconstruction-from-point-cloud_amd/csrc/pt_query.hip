@@ -170,10 +170,113 @@ __device__ inline uint32_t cell_key(const GridParams& gp, int x, int y, int z) {
   return (pt_block_id(gp.mdim, x, y, z) << 9) + pt_local_cell(x, y, z);
 }
 
+// =====================================================================================================================
+// Search over the REFINED grid (pt_refine.hip), used by the group kernel (knn_kernel<.., HIER = true>): a cell that carries a node
+// is not scanned end to end but descended into.  Inside a node the 64 rows of sub-cells are tested against the current bound
+// eight at a time (one lane each), the surviving rows are cut to the sub-cells the bound still reaches, leaf sub-cells are scanned
+// as before and sub-cells that are nodes themselves are descended into the same way (PT_REFINE_DEPTH levels).  The sub-cell that
+// holds the target is visited FIRST on every level, so the bound is tight before the neighbours are looked at; it is skipped when
+// the sweep over the rows comes by, so no point is ever offered twice.  Exact for the same reason the group kernel is: a box is
+// skipped only if Distance::min_distance_to_rectangle (reference src/Distance.h:27-57) of it exceeds the current k-th distance.
+template <class Rec, int KPL>
+struct HierScan {
+  const GridParams& gp;
+  const Rec* __restrict__ src;
+  const uint32_t* __restrict__ nodes;
+  const TargetGeom& T;
+  TopList<KPL>& top;
+  int gshift;
+
+  __device__ void range(uint32_t s, uint32_t e) {
+    for (uint32_t base = s; base < e; base += GL) {
+      const uint32_t p = base + (uint32_t)top.L;
+      double d = INFINITY;
+      uint32_t id = PT_NOIDX_U;
+      if (p < e) { const Rec r = src[p]; d = dist2(T.q, r); id = r.id; }
+      top.offer(d, id, gshift);
+    }
+  }
+  // squared distance (cell units) from the target to the interval [lo, hi] on axis a, under-estimated by the slack
+  __device__ double gap2(int a, double lo, double hi) const {
+    const double g = fmax(fmax(lo - T.u[a], T.u[a] - hi) - PT_CELL_EPS, 0.0);
+    return g * g;
+  }
+  template <int DEPTH>
+  __device__ void node(uint32_t nid) {
+    const uint32_t* __restrict__ N = nodes + (size_t)(nid - 1u) * PT_NODE_WORDS;
+    const double* hd = reinterpret_cast<const double*>(N);
+    const double ox = hd[0], oy = hd[1], oz = hd[2], inv = hd[3], w = 1.0 / inv;     // w: sub-cell side in cell units (a power of 1/8: exact)
+    // the sub-cell the target falls in, if it is inside this node's box
+    const double rx = (T.u[0] - ox) * inv, ry = (T.u[1] - oy) * inv, rz = (T.u[2] - oz) * inv;
+    const bool inside = rx >= 0.0 && rx < 8.0 && ry >= 0.0 && ry < 8.0 && rz >= 0.0 && rz < 8.0;
+    const uint32_t own = inside ? (uint32_t)(((int)rz << 6) | ((int)ry << 3) | (int)rx) : 0xFFFFFFFFu;
+    // Sweep: step -1 is the target's own sub-cell alone (so that the bound is tight before anything else is looked at), steps
+    // 0..7 are the 64 rows (sy, sz) of eight sub-cells, eight rows per step, one lane testing each; the own sub-cell is skipped
+    // when its row comes by.  One code path serves both, so that the scan and the descent are instantiated once per level.
+    for (int step = inside ? -1 : 0; step < 64 / GL; ++step) {
+      uint32_t mask = 1u;
+      if (step >= 0) {
+        const int row = step * GL + top.L, sy = row & 7, sz = row >> 3;
+        const double s2 = gap2(1, oy + (double)sy * w, oy + (double)(sy + 1) * w) + gap2(2, oz + (double)sz * w, oz + (double)(sz + 1) * w);
+        const bool live = !(s2 * T.h2 > top.lim_d) && N[PT_NODE_START + row * 8] != N[PT_NODE_START + row * 8 + 8];     // (and not empty)
+        mask = (uint32_t)((__ballot(live) >> gshift) & 0xFFull);
+      }
+      while (mask) {                                        // group-uniform
+        const int j = __ffs((int)mask) - 1;
+        mask &= mask - 1;
+        int r2, xa, xb;
+        if (step < 0) { r2 = (int)(own >> 3); xa = xb = (int)(own & 7u); }
+        else {
+          r2 = step * GL + j;
+          const int y2 = r2 & 7, z2 = r2 >> 3;
+          const double t2 = gap2(1, oy + (double)y2 * w, oy + (double)(y2 + 1) * w) + gap2(2, oz + (double)z2 * w, oz + (double)(z2 + 1) * w);
+          if (t2 * T.h2 > top.lim_d) continue;              // the bound may have tightened since the ballot
+          xa = 0; xb = 7;
+          while (xa <= xb && (gap2(0, ox + (double)xa * w, ox + (double)(xa + 1) * w) + t2) * T.h2 > top.lim_d) ++xa;
+          while (xb >= xa && (gap2(0, ox + (double)xb * w, ox + (double)(xb + 1) * w) + t2) * T.h2 > top.lim_d) --xb;
+        }
+        // leaf sub-cells next to each other are one contiguous run of records, scanned in one go; a sub-cell that is a node, the
+        // own sub-cell (already done) and the end of the row cut the run
+        uint32_t run_s = 0, run_e = 0;
+        for (int x = xa; x <= xb + 1; ++x) {
+          const uint32_t sub = (uint32_t)(r2 * 8 + x);
+          uint32_t child = 0;
+          bool cut = x > xb || (step >= 0 && sub == own);
+          if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) { if (!cut) { child = N[PT_NODE_CHILD + sub]; cut = child != 0u; } }
+          if (!cut) {
+            if (run_e == run_s) run_s = N[PT_NODE_START + sub];
+            run_e = N[PT_NODE_START + sub + 1];
+            continue;
+          }
+          if (run_e > run_s) range(run_s, run_e);
+          run_s = run_e = 0;
+          if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) { if (child) node<DEPTH + 1>(child); }
+        }
+      }
+    }
+  }
+};
+
+// Heavy cells met by the group kernel (HIER builds) are not scanned on the spot but remembered -- their key, in the group's slice of
+// an LDS list -- and descended into at ONE place of the kernel (the descent is three levels of inlined code: one copy is enough).
+constexpr int PEND_CAP = 32;
+struct Pending {
+  uint32_t* slot;          // this group's PEND_CAP words of LDS
+  uint32_t n;              // group-uniform
+  uint32_t thr;            // cells with more points than this may carry a node (0xFFFFFFFF: the grid has none)
+  __device__ bool heavy(uint32_t s, uint32_t e) const { return e - s > thr; }
+  __device__ bool push(uint32_t key, int lane) {           // false: list full, the caller scans the cell linearly (exact, only slower)
+    if (n >= (uint32_t)PEND_CAP) return false;
+    if (lane == 0) slot[n] = key;
+    ++n;
+    return true;
+  }
+};
+
 // generic walk of cells [xa, xb] x {y} x {z} (inside the grid): prune by the box lower bound, then scan block by block
 template <class Rec, int KPL>
 __device__ void scan_row_generic(const GridParams& gp, const Rec* __restrict__ src, const uint32_t* __restrict__ cs, const TargetGeom& T,
-                                 TopList<KPL>& top, int gshift, int xa, int xb, int y, int z) {
+                                 TopList<KPL>& top, int gshift, int xa, int xb, int y, int z, Pending* pend = nullptr) {
   const double gy = T.gap(1, y, y), gz = T.gap(2, z, z);
   const double s2 = gy * gy + gz * gz;
   if (s2 * T.h2 > top.lim_d) return;
@@ -183,7 +286,26 @@ __device__ void scan_row_generic(const GridParams& gp, const Rec* __restrict__ s
   for (int bx = xa >> 3; bx <= (xb >> 3); ++bx) {
     const int pa = max(xa, bx << 3), pb = min(xb, (bx << 3) + 7);
     const uint32_t key = cell_key(gp, pa, y, z);
-    const uint32_t s = cs[key], e = cs[key + (uint32_t)(pb - pa) + 1u];
+    uint32_t s = cs[key], e = cs[key + (uint32_t)(pb - pa) + 1u];
+    if (pend && pend->heavy(s, e)) {
+      // a run that may hold heavy cells: those are set aside for the descent, the light ones in between are scanned here
+      const uint32_t e_all = e;
+      e = s;
+      for (int i = 0; i <= pb - pa; ++i) {
+        const uint32_t s1 = cs[key + (uint32_t)i], e1 = cs[key + (uint32_t)i + 1u];
+        const bool defer = pend->heavy(s1, e1) && pend->push(key + (uint32_t)i, top.L);
+        if (!defer) { e = e1; continue; }
+        for (uint32_t base = s; base < e; base += GL) {       // flush the light run collected so far
+          const uint32_t p = base + top.L;
+          double d = INFINITY;
+          uint32_t id = PT_NOIDX_U;
+          if (p < e) { const Rec r = src[p]; d = dist2(T.q, r); id = r.id; }
+          top.offer(d, id, gshift);
+        }
+        s = e = e1;
+      }
+      (void)e_all;
+    }
     for (uint32_t base = s; base < e; base += GL) {
       const uint32_t p = base + top.L;
       double d = INFINITY;
@@ -209,12 +331,16 @@ struct RowPlan {
   __device__ uint32_t addr(uint32_t v) const { return v < n0 ? a0 + v : (v < n01 ? a1 + (v - n0) : a2 + (v - n01)); }
 };
 
-template <class Rec, int KPL>
-__global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __restrict__ src, const uint32_t* __restrict__ cs,
+// HIER: the grid carries refined cells (pt_refine.hip: cell_node / nodes / node_thr).  Cells with more than node_thr points are then
+// left out of the flat scans, remembered in the group's pending list and descended into (HierScan) at the head of the ring loop.
+struct HierArgs { const uint32_t* cell_node; const uint32_t* nodes; uint32_t thr; };
+template <class Rec, int KPL, bool HIER>
+__global__ __launch_bounds__(WG, HIER ? (KPL == 4 ? 3 : 4) : 1) void knn_kernel(GridParams gp, const Rec* __restrict__ src, const uint32_t* __restrict__ cs,
                                                  const Rec* __restrict__ tgt, uint32_t m, int k, const double* __restrict__ bound2,
                                                  uint32_t* __restrict__ out_idx, double* __restrict__ out_d2,
-                                                 const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_n) {
+                                                 const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_n, HierArgs ha) {
   constexpr int NB = Batch<Rec>::N;
+  __shared__ uint32_t pend_lds[HIER ? (WG / GL) * PEND_CAP : 1];
   const uint32_t gid = (blockIdx.x * WG + threadIdx.x) / GL;
   if (gid >= (list ? *list_n : m)) return;    // whole groups leave together
   const int L = threadIdx.x & (GL - 1);
@@ -231,6 +357,8 @@ __global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __res
   TopList<KPL> top;
   top.init(L, k, bound2 ? bound2[tr.id] : INFINITY);
   const int c0 = T.c[0], c1 = T.c[1], c2 = T.c[2];
+  Pending pend{&pend_lds[HIER ? (threadIdx.x / GL) * PEND_CAP : 0], 0u, HIER ? ha.thr : 0xFFFFFFFFu};
+  Pending* const pp = HIER ? &pend : nullptr;
 
   // ---- ring 1, phase A: cell ranges of the 9 rows.  Every lane looks up the centre row (row 0); lane L also
   //      looks up row L+1.  12 independent loads per lane, one memory latency for the whole neighbourhood.
@@ -278,6 +406,15 @@ __global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __res
       const int x = c0 - 1 + j;
       const double g = T.gap(0, x, x);
       n[j] = ((g * g + s2) * T.h2 > top.lim_d) ? 0u : (E[j] - S[j]);   // cells outside the grid have S == E == 0
+    }
+    if constexpr (HIER) {
+      // heavy cells leave the flat plan for the pending list; the middle cell first, so that in row 0 (planned first) the target's
+      // own cell heads the list and its descent tightens the bound for all the others
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        const int j = jj == 0 ? 1 : (jj == 1 ? 0 : 2);
+        if (n[j] && pend.heavy(S[j], E[j]) && pend.push(cell_key(gp, c0 - 1 + j, y, z), L)) n[j] = 0u;
+      }
     }
     P.a0 = S[0]; P.a1 = S[1]; P.a2 = S[2];
     P.n0 = n[0]; P.n01 = n[0] + n[1]; P.T = P.n01 + n[2];
@@ -332,6 +469,27 @@ __global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __res
   // ---- rings >= 2: only while something outside the scanned box can still beat the limit ---------------------------
   const int ring_limit = max(PT_RING_LIMIT, (int)cbrtf(0.07f * (float)gp.nblocks));
   for (int r = 1;; ++r) {
+    if constexpr (HIER) {
+      // the heavy cells of the ring just scanned (ring 1 on the first pass): descended into here, the ONLY place -- before the
+      // termination test, which therefore sees the bound they leave
+      if (pend.n) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // lane 0's list entries, for the whole group
+        __builtin_amdgcn_wave_barrier();
+        HierScan<Rec, KPL> H{gp, src, ha.nodes, T, top, gshift};
+        for (uint32_t i = 0; i < pend.n; ++i) {
+          const uint32_t key = pend.slot[i];
+          int x, y, z;
+          pt_decode_cell(gp, key, x, y, z);
+          const double gx = T.gap(0, x, x), gy = T.gap(1, y, y), gz = T.gap(2, z, z);
+          if ((gx * gx + gy * gy + gz * gz) * T.h2 > top.lim_d) continue;      // the bound has tightened since the cell was set aside
+          const uint32_t nid = ha.cell_node[key];
+          if (nid) H.template node<0>(nid); else H.range(cs[key], cs[key + 1]);   // (no node: the table was full when the cell asked)
+        }
+        pend.n = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // the next ring's entries stay behind these reads
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
     // every unscanned point lies beyond one of the box faces that still has cells behind it
     bool covered = true;
     double dout = INFINITY;
@@ -387,10 +545,10 @@ __global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __res
     for (int z = z0; z <= z1; ++z)
       for (int y = y0; y <= y1; ++y) {
         const bool shell = (z == c2 - rr) || (z == c2 + rr) || (y == c1 - rr) || (y == c1 + rr);
-        if (shell) scan_row_generic<Rec, KPL>(gp, src, cs, T, top, gshift, x0, x1, y, z);
+        if (shell) scan_row_generic<Rec, KPL>(gp, src, cs, T, top, gshift, x0, x1, y, z, pp);
         else {
-          if (c0 - rr >= 0) scan_row_generic<Rec, KPL>(gp, src, cs, T, top, gshift, c0 - rr, c0 - rr, y, z);
-          if (c0 + rr <= gp.dim[0] - 1) scan_row_generic<Rec, KPL>(gp, src, cs, T, top, gshift, c0 + rr, c0 + rr, y, z);
+          if (c0 - rr >= 0) scan_row_generic<Rec, KPL>(gp, src, cs, T, top, gshift, c0 - rr, c0 - rr, y, z, pp);
+          if (c0 + rr <= gp.dim[0] - 1) scan_row_generic<Rec, KPL>(gp, src, cs, T, top, gshift, c0 + rr, c0 + rr, y, z, pp);
         }
       }
   }
@@ -405,7 +563,6 @@ __global__ __launch_bounds__(WG) void knn_kernel(GridParams gp, const Rec* __res
     }
   }
 }
-
 
 // =====================================================================================================================
 // Tile kernel: one 8x8x8-cell block per workgroup, candidates staged in LDS, FOUR LANES (a DPP quad) PER TARGET.
@@ -1058,17 +1215,37 @@ void pt_launch_knn(const GridParams& gp, const Rec* src, const uint32_t* cell_st
                    uint32_t* out_idx, double* out_d2, const uint32_t* list, const uint32_t* list_n, hipStream_t s) {
   if (!m) return;
   const uint32_t nwg = (uint32_t)(((uint64_t)m * GL + WG - 1) / WG);
+  const HierArgs ha{nullptr, nullptr, 0xFFFFFFFFu};
   if (k <= 8)
-    hipLaunchKernelGGL((knn_kernel<Rec, 1>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n);
+    hipLaunchKernelGGL((knn_kernel<Rec, 1, false>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n, ha);
   else if (k <= 16)
-    hipLaunchKernelGGL((knn_kernel<Rec, 2>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n);
+    hipLaunchKernelGGL((knn_kernel<Rec, 2, false>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n, ha);
   else
-    hipLaunchKernelGGL((knn_kernel<Rec, 4>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n);
+    hipLaunchKernelGGL((knn_kernel<Rec, 4, false>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n, ha);
 }
 template void pt_launch_knn<RecF>(const GridParams&, const RecF*, const uint32_t*, const RecF*, uint32_t, int, const double*, uint32_t*, double*,
                                   const uint32_t*, const uint32_t*, hipStream_t);
 template void pt_launch_knn<RecD>(const GridParams&, const RecD*, const uint32_t*, const RecD*, uint32_t, int, const double*, uint32_t*, double*,
                                   const uint32_t*, const uint32_t*, hipStream_t);
+
+template <class Rec>
+void pt_launch_knn_hier(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const uint32_t* cell_node, const uint32_t* nodes, uint32_t node_thr,
+                        const Rec* tgt, uint32_t m, int k, const double* bound2, uint32_t* out_idx, double* out_d2, const uint32_t* list,
+                        const uint32_t* list_n, hipStream_t s) {
+  if (!m) return;
+  const uint32_t nwg = (uint32_t)(((uint64_t)m * GL + WG - 1) / WG);
+  const HierArgs ha{cell_node, nodes, node_thr};
+  if (k <= 8)
+    hipLaunchKernelGGL((knn_kernel<Rec, 1, true>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n, ha);
+  else if (k <= 16)
+    hipLaunchKernelGGL((knn_kernel<Rec, 2, true>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n, ha);
+  else
+    hipLaunchKernelGGL((knn_kernel<Rec, 4, true>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n, ha);
+}
+template void pt_launch_knn_hier<RecF>(const GridParams&, const RecF*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const RecF*, uint32_t, int, const double*,
+                                       uint32_t*, double*, const uint32_t*, const uint32_t*, hipStream_t);
+template void pt_launch_knn_hier<RecD>(const GridParams&, const RecD*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const RecD*, uint32_t, int, const double*,
+                                       uint32_t*, double*, const uint32_t*, const uint32_t*, hipStream_t);
 
 // tile kernel over all blocks; targets it cannot settle are appended to todo[*todo_n] (todo_n zeroed by the caller).
 // geometry 1 = the two-workgroups-per-CU geometry (regions of <= PT_TILE_CAP_SMALL_* records), 0 = large.  With `attr` the

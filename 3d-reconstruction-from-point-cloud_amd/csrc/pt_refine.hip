@@ -1,0 +1,162 @@
+// pt_refine.hip -- adaptive refinement of the cell grid for clouds with strong density contrast (gfx950 / MI355X).
+//
+// The reference's kd-tree (CGAL Kd_tree behind `Tree tree(points.begin(), points.end())`, src/pointsTransfer.cpp:259) adapts to
+// the local density by construction; a dense uniform grid does not: in a cloud of surfaces and clusters (BASELINE config 5)
+// single cells hold 10^3..10^5 points while most are empty, and every query near them scans whole cells.  This file puts an
+// 8 x 8 x 8 sub-grid inside every HEAVY cell (more than `threshold` points), recursively (up to PT_REFINE_DEPTH levels):
+//   * the records of a heavy cell are counting-sorted by sub-cell IN PLACE inside the cell's own range of the sorted array --
+//     the level-0 table (cell_start) stays valid, so the tile kernel and every level-0 scan work unchanged;
+//   * every refined cell ("node") gets a 513-entry table of sub-cell starts and a 512-entry table of child nodes;
+//   * membership: sub = clamp(floor((u - node origin) * cells-per-unit), 0, 7) per axis with u = (p - bbmin) / h, the position
+//     in level-0 cell units; origins and scales are dyadic rationals, exact in fp64, and the query computes the very same
+//     expression, so build and search agree on every point.
+// The search over this structure (HierScan, used by the group kernel knn_kernel<.., HIER = true>) is in pt_query.hip.
+#include "pt_internal.h"
+
+namespace {
+
+constexpr int RW = 512;            // refine workgroup: one thread per sub-cell in the scan
+constexpr int RITEMS = 12;         // records a thread keeps in registers: nodes up to 6144 points are read once
+
+__device__ inline void node_header(uint32_t* node, double ox, double oy, double oz, double inv, uint32_t s, uint32_t e) {
+  double* h = reinterpret_cast<double*>(node);
+  h[0] = ox; h[1] = oy; h[2] = oz; h[3] = inv;
+  node[PT_NODE_START] = s;                 // provisional: the refine kernel overwrites the start table
+  node[PT_NODE_START + 512] = e;
+}
+
+// level 0: every cell with more than `threshold` points becomes a node
+__global__ __launch_bounds__(256) void heavy_cells_kernel(GridParams gp, const uint32_t* __restrict__ cs, uint32_t ncells, uint32_t threshold,
+                                                          uint32_t* __restrict__ cell_node, uint32_t* __restrict__ node_count, uint32_t node_cap,
+                                                          uint32_t* __restrict__ nodes) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncells) return;
+  const uint32_t s = cs[c], e = cs[c + 1];
+  uint32_t id = 0;
+  if (e - s > threshold) {
+    const uint32_t slot = atomicAdd(node_count, 1u);
+    if (slot < node_cap) {
+      int cx, cy, cz;
+      pt_decode_cell(gp, c, cx, cy, cz);
+      node_header(nodes + (size_t)slot * PT_NODE_WORDS, (double)cx, (double)cy, (double)cz, 8.0, s, e);
+      id = slot + 1;
+    }
+  }
+  cell_node[c] = id;
+}
+
+// deeper levels: heavy sub-cells of the nodes [n0, n1) become nodes themselves
+__global__ __launch_bounds__(RW) void heavy_subcells_kernel(uint32_t n0, uint32_t threshold, uint32_t* __restrict__ node_count, uint32_t node_cap,
+                                                            uint32_t* __restrict__ nodes) {
+  uint32_t* N = nodes + (size_t)(n0 + blockIdx.x) * PT_NODE_WORDS;
+  const uint32_t sub = threadIdx.x;
+  const uint32_t s = N[PT_NODE_START + sub], e = N[PT_NODE_START + sub + 1];
+  uint32_t id = 0;
+  if (e - s > threshold) {
+    const uint32_t slot = atomicAdd(node_count, 1u);
+    if (slot < node_cap) {
+      const double* h = reinterpret_cast<const double*>(N);
+      const double inv = h[3];
+      node_header(nodes + (size_t)slot * PT_NODE_WORDS, h[0] + (double)(sub & 7u) / inv, h[1] + (double)((sub >> 3) & 7u) / inv,
+                  h[2] + (double)(sub >> 6) / inv, inv * 8.0, s, e);
+      id = slot + 1;
+    }
+  }
+  N[PT_NODE_CHILD + sub] = id;
+}
+
+template <class Rec>
+__device__ inline uint32_t subcell_of(const GridParams& gp, const Rec& r, double ox, double oy, double oz, double inv) {
+  // raw (unclamped) position in level-0 cell units, as pt_cell_axis computes it before clamping; the sub-cell index is clamped
+  const double ux = ((double)r.x - gp.bbmin[0]) * gp.inv_h, uy = ((double)r.y - gp.bbmin[1]) * gp.inv_h, uz = ((double)r.z - gp.bbmin[2]) * gp.inv_h;
+  const int sx = (int)fmin(fmax(floor((ux - ox) * inv), 0.0), 7.0), sy = (int)fmin(fmax(floor((uy - oy) * inv), 0.0), 7.0),
+            sz = (int)fmin(fmax(floor((uz - oz) * inv), 0.0), 7.0);
+  return (uint32_t)((sz << 6) | (sy << 3) | sx);
+}
+
+// one workgroup per node: counting sort of the node's records by sub-cell, in place; writes the node's start table
+template <class Rec>
+__global__ __launch_bounds__(RW) void refine_nodes_kernel(GridParams gp, Rec* __restrict__ rec, Rec* __restrict__ tmp, uint32_t n0, uint32_t* __restrict__ nodes) {
+  __shared__ uint32_t cnt[512];
+  __shared__ uint32_t wsum[RW / 64];
+  uint32_t* N = nodes + (size_t)(n0 + blockIdx.x) * PT_NODE_WORDS;
+  const double* h = reinterpret_cast<const double*>(N);
+  const double ox = h[0], oy = h[1], oz = h[2], inv = h[3];
+  const uint32_t s = N[PT_NODE_START], e = N[PT_NODE_START + 512];
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const bool in_regs = (e - s) <= (uint32_t)(RW * RITEMS);
+  Rec r[RITEMS];
+  uint32_t sc[RITEMS];
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < RITEMS; ++j) {
+      const uint32_t i = s + j * RW + threadIdx.x;
+      if (i < e) { r[j] = rec[i]; sc[j] = subcell_of(gp, r[j], ox, oy, oz, inv); atomicAdd(&cnt[sc[j]], 1u); }
+    }
+  } else {
+    for (uint32_t i = s + threadIdx.x; i < e; i += RW) atomicAdd(&cnt[subcell_of(gp, rec[i], ox, oy, oz, inv)], 1u);
+  }
+  __syncthreads();
+  const uint32_t c0 = cnt[threadIdx.x];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t incl = wave_incl_scan(c0);
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  uint32_t off = 0;
+#pragma unroll
+  for (int i = 0; i < RW / 64; ++i) if (i < w) off += wsum[i];
+  const uint32_t ex = off + incl - c0;
+  __syncthreads();
+  cnt[threadIdx.x] = ex;                                    // cursor, relative to s
+  N[PT_NODE_START + threadIdx.x] = s + ex;                  // (entry 512 = e is already there)
+  __syncthreads();
+  if (in_regs) {                                            // everything is in registers: the range can be rewritten in place
+#pragma unroll
+    for (int j = 0; j < RITEMS; ++j) {
+      const uint32_t i = s + j * RW + threadIdx.x;
+      if (i < e) rec[s + atomicAdd(&cnt[sc[j]], 1u)] = r[j];
+    }
+  } else {                                                  // big node: through the scratch array, then back (one workgroup owns the range)
+    for (uint32_t i = s + threadIdx.x; i < e; i += RW) {
+      const Rec v = rec[i];
+      tmp[s + atomicAdd(&cnt[subcell_of(gp, v, ox, oy, oz, inv)], 1u)] = v;
+    }
+    __threadfence();
+    __syncthreads();
+    for (uint32_t i = s + threadIdx.x; i < e; i += RW) rec[i] = tmp[i];
+  }
+}
+
+// fp64 clouds: the fp32 shadow of the sorted records (id = sorted position) after refinement has moved records inside their cells
+__global__ __launch_bounds__(256) void reshadow_kernel(const RecD* __restrict__ rec, uint32_t n, RecF* __restrict__ shadow) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const RecD v = rec[i];
+  RecF o;
+  o.x = (float)v.x; o.y = (float)v.y; o.z = (float)v.z; o.id = i;
+  shadow[i] = o;
+}
+
+}  // namespace
+
+void pt_launch_heavy_cells(const GridParams& gp, const uint32_t* cs, uint32_t ncells, uint32_t threshold, uint32_t* cell_node, uint32_t* node_count,
+                           uint32_t node_cap, uint32_t* nodes, hipStream_t s) {
+  if (!ncells) return;
+  hipLaunchKernelGGL(heavy_cells_kernel, dim3((ncells + 255) / 256), dim3(256), 0, s, gp, cs, ncells, threshold, cell_node, node_count, node_cap, nodes);
+}
+void pt_launch_heavy_subcells(uint32_t n0, uint32_t n1, uint32_t threshold, uint32_t* node_count, uint32_t node_cap, uint32_t* nodes, hipStream_t s) {
+  if (n1 <= n0) return;
+  hipLaunchKernelGGL(heavy_subcells_kernel, dim3(n1 - n0), dim3(RW), 0, s, n0, threshold, node_count, node_cap, nodes);
+}
+template <class Rec>
+void pt_launch_refine_nodes(const GridParams& gp, Rec* rec, Rec* tmp, uint32_t n0, uint32_t n1, uint32_t* nodes, hipStream_t s) {
+  if (n1 <= n0) return;
+  hipLaunchKernelGGL(refine_nodes_kernel<Rec>, dim3(n1 - n0), dim3(RW), 0, s, gp, rec, tmp, n0, nodes);
+}
+template void pt_launch_refine_nodes<RecF>(const GridParams&, RecF*, RecF*, uint32_t, uint32_t, uint32_t*, hipStream_t);
+template void pt_launch_refine_nodes<RecD>(const GridParams&, RecD*, RecD*, uint32_t, uint32_t, uint32_t*, hipStream_t);
+void pt_launch_reshadow(const RecD* rec, uint32_t n, RecF* shadow, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(reshadow_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rec, n, shadow);
+}

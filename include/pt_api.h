@@ -88,6 +88,10 @@ typedef struct pt_stats_t {
   int32_t bbox_guess;       /* last build: 0 the bounding box came from a pass of its own; 1 the grid was laid out from a sampled
                              * box and pass 1 verified it (big clouds); -1 the sampled box was too small and the build was redone */
   double ms_bake;           /* texture bake (+ edge padding) of the last pt_bake_texture, device time */
+  uint32_t n_nodes;         /* last build: refined ("heavy") cells and sub-cells that carry an 8x8x8 sub-grid (0: none needed) */
+  int32_t refine_levels;    /* ... and how many levels deep (<= 3) */
+  uint32_t max_cell_points; /* points of the fullest grid cell of the last build (adaptive builds) */
+  uint32_t _pad2;
 } pt_stats_t;
 
 /* ---- context ------------------------------------------------------------------------ */
@@ -104,7 +108,9 @@ int  pt_set_stream(pt_ctx*, void* hip_stream);
  * size when non-empty cells hold far more than rho points, default; needs one host read-back per build), "tile" (0 = group kernel only, 1 = tile kernel +
  * group kernel for its leftovers with the geometry chosen from the cell density (default), 2 / 3 = force the small /
  * large tile geometry), "guess_min_points" (clouds at least this large lay their grid out from the bounding box of a
- * sample and verify it during the first partition pass instead of spending a pass on the exact box; default 8 Mi). */
+ * sample and verify it during the first partition pass instead of spending a pass on the exact box; default 8 Mi),
+ * "refine_threshold" (grid cells holding more points than this get an 8x8x8 sub-grid, recursively up to three levels, which
+ * searches descend into instead of scanning the cell end to end -- clouds with strong density contrast; default 2048, 0 = never). */
 int  pt_set_param(pt_ctx*, const char* name, double value);
 const char* pt_last_error(pt_ctx*);
 int  pt_stats(pt_ctx*, pt_stats_t* out);

@@ -1070,3 +1070,67 @@ def test_cli_sharded_path(tmp_path, pkg, oracle, gpus):
     a, b = rows(d1), rows(d2_)
     assert np.abs(a[:, 8:] - b[:, 8:]).max() <= 1 and np.abs(a[:, :8] - b[:, :8]).max() <= 2e-5
     assert not [f for f in os.listdir("/tmp") if f.startswith("pointsTransfer.") and os.path.isdir(os.path.join("/tmp", f)) and os.stat(os.path.join("/tmp", f)).st_uid == os.getuid() and not os.listdir(os.path.join("/tmp", f))] or True
+
+
+# ---- refined cells (pt_refine.hip): sub-grids inside heavy cells, descended into by the group kernel ---------------------------
+@pytest.mark.parametrize("kind,k,f64,thr", [("blobs", 8, False, 24), ("blobs", 32, True, 64), ("sheet", 20, False, 3), ("lattice", 8, False, 8),
+                                            ("line", 16, True, 3), ("uniform", 8, False, 2)])
+def test_refined_cells_are_exact(pkg, oracle, kind, k, f64, thr):
+    """A low threshold forces nodes everywhere (three levels deep on the clumps): unbounded and radius-bounded searches over the
+    refined grid equal brute force bit for bit -- duplicates (lattice: thousands of identical points per node), points on cell
+    faces, targets far outside, k above a node's population."""
+    import torch
+    from test_gpu_stress import _cloud
+    rng = np.random.default_rng(77 + k)
+    n, m = 60000, 3000
+    src = _cloud(rng, kind, n); tgt = _cloud(rng, kind, m)
+    tgt[:, :100] = tgt[:, :100] * np.float32(3.0) - np.float32(1.0)            # some targets outside the cloud
+    tgt[:, 100:400] = src[:, rng.integers(0, n, 300)]                          # and some exactly on source points
+    if f64:
+        src = src.astype(np.float64) + (rng.random(src.shape) - 0.5) * 1e-9 * (kind != "lattice"); tgt = tgt.astype(np.float64)
+    want = oracle.knn_bruteforce(src, tgt, k)
+    for tile in (0, 1):                                                        # group kernel alone / tile kernel + refined leftovers
+        with pkg.PointsTransfer(device=0, k_hint=k) as p:
+            p.set_param("refine_threshold", thr); p.set_param("tile", tile)
+            p.build(src)
+            st = p.stats()
+            assert st["n_nodes"] > 0 and st["refine_levels"] >= 1 and st["max_cell_points"] > thr, st
+            got = p.query(tgt, k)
+            _check_exact(got, want, "refined %s tile=%d" % (kind, tile))
+            # radius-bounded (what a slab answers for another rank): the bound of every other row halved -> those rows come back shorter
+            bnd = want[1][:, k - 1].copy(); bnd[::2] *= 0.5
+            xt = pkg.F64 if f64 else pkg.F32
+            x = torch.from_numpy(np.ascontiguousarray(tgt)).cuda(); b = torch.from_numpy(bnd).cuda()
+            bi = torch.empty((m, k), dtype=torch.int32, device="cuda"); bd = torch.empty((m, k), dtype=torch.float64, device="cuda")
+            p.query_bounded_dev(x, xt, b, m, k, bi, bd)
+            torch.cuda.synchronize()
+            bi = bi.cpu().numpy().view(np.uint32); bd = bd.cpu().numpy()
+            keep = want[1] <= bnd[:, None]
+            assert np.array_equal(np.where(keep, want[0], 0xFFFFFFFF), bi) and np.array_equal(np.where(keep, want[1], np.inf), bd)
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:                           # the refinement changes nothing but the speed
+        p.set_param("refine_threshold", 0)
+        p.build(src)
+        assert p.stats()["n_nodes"] == 0
+        _check_exact(p.query(tgt, k), want, "unrefined %s" % kind)
+
+
+def test_full_size_clustered_sampled_against_oracle(pkg, oracle):
+    """BASELINE config 5's distribution at 100 M points (thin patches + blobs + a little uniform; cells of the fullest clump hold tens
+    of thousands of points and get sub-grids): the search of 5 M jittered targets is exact on a sample against the CPU kd-tree."""
+    import torch
+    n, m, k, seed = 100_000_000, 5_000_000, 8, 0xC5
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.build_synth(n, seed, dist=pkg.capi.DIST_CLUSTERED)
+        p.targets_synth(m, seed, dist=pkg.capi.DIST_CLUSTERED)
+        st = p.stats()
+        assert st["n_nodes"] > 0 and st["max_cell_points"] > 2048
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        p.query_resident_dev(k, idx, d2)
+        torch.cuda.synchronize()
+        assert bool((d2[:, 1:] >= d2[:, :-1]).all())
+        sel = np.random.default_rng(2).choice(m, 4000, replace=False)
+        I = idx[torch.from_numpy(sel).cuda()].cpu().numpy().view(np.uint32); D = d2[torch.from_numpy(sel).cuda()].cpu().numpy()
+    src = oracle.synth_xyz(seed, 0, n, dist=1, n_total=n, m_total=m)
+    tgt = np.concatenate([oracle.synth_xyz(seed, 1, 1, i0=int(t), dist=1, n_total=n, m_total=m) for t in sel], axis=1)
+    wi, wd = oracle.KdTree(src).query(tgt, k)
+    assert np.array_equal(I, wi) and np.array_equal(D, wd)
