@@ -22,9 +22,9 @@
 #define PT_CELL_EPS 1e-9            // slack (in cell units) on every cell-box bound: cell membership is
                                     // computed in fp64 with ~1e-12 cell units of rounding at most
 
-// refined ("heavy") cells, pt_refine.hip: one node = header {origin x, y, z in level-0 cell units, sub-cells per cell unit} as four
-// doubles, 513 absolute starts of its 8 x 8 x 8 sub-cells (sub = sz << 6 | sy << 3 | sx), 512 child node ids (id + 1, 0 = leaf)
-#define PT_NODE_START 8
+// refined ("heavy") cells, pt_refine.hip: one node = header {origin x, y, z in level-0 cell units, sub-cells per cell unit, sub-cell
+// side in cell units} as five doubles, 513 absolute starts of its 8 x 8 x 8 sub-cells (sub = sz << 6 | sy << 3 | sx), 512 child node ids (id + 1, 0 = leaf)
+#define PT_NODE_START 10
 #define PT_NODE_CHILD (PT_NODE_START + 513)
 #define PT_NODE_WORDS 1040
 #define PT_REFINE_DEPTH 3           // levels below the grid: sub-cells of 1/8, 1/64, 1/512 of a cell side

@@ -205,7 +205,7 @@ struct HierScan {
   __device__ void node(uint32_t nid) {
     const uint32_t* __restrict__ N = nodes + (size_t)(nid - 1u) * PT_NODE_WORDS;
     const double* hd = reinterpret_cast<const double*>(N);
-    const double ox = hd[0], oy = hd[1], oz = hd[2], inv = hd[3], w = 1.0 / inv;     // w: sub-cell side in cell units (a power of 1/8: exact)
+    const double ox = hd[0], oy = hd[1], oz = hd[2], inv = hd[3], w = hd[4];        // w = 1 / inv: sub-cell side in cell units (a power of 1/8)
     // the sub-cell the target falls in, if it is inside this node's box
     const double rx = (T.u[0] - ox) * inv, ry = (T.u[1] - oy) * inv, rz = (T.u[2] - oz) * inv;
     const bool inside = rx >= 0.0 && rx < 8.0 && ry >= 0.0 && ry < 8.0 && rz >= 0.0 && rz < 8.0;
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
         }
       }
     };
-    if constexpr (K > 16 && WIDE) {                   // (the wide variant's register budget: one ranking body only)
+    if constexpr (K > 16 && (WIDE || (BLEND && DBL))) {   // (register budget of the wide and of the fp64 + blend variants: one ranking body only)
       rank_all([](double ad, uint32_t ai, double bd, uint32_t bi) { return key_lt(ad, ai, bd, bi); });
     } else {
       rank_all([](double ad, uint32_t, double bd, uint32_t) { return ad < bd; });

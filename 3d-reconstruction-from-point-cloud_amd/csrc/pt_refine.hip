@@ -20,7 +20,7 @@ constexpr int RITEMS = 12;         // records a thread keeps in registers: nodes
 
 __device__ inline void node_header(uint32_t* node, double ox, double oy, double oz, double inv, uint32_t s, uint32_t e) {
   double* h = reinterpret_cast<double*>(node);
-  h[0] = ox; h[1] = oy; h[2] = oz; h[3] = inv;
+  h[0] = ox; h[1] = oy; h[2] = oz; h[3] = inv; h[4] = 1.0 / inv;      // (a power of 1/8: exact)
   node[PT_NODE_START] = s;                 // provisional: the refine kernel overwrites the start table
   node[PT_NODE_START + 512] = e;
 }
@@ -56,9 +56,9 @@ __global__ __launch_bounds__(RW) void heavy_subcells_kernel(uint32_t n0, uint32_
     const uint32_t slot = atomicAdd(node_count, 1u);
     if (slot < node_cap) {
       const double* h = reinterpret_cast<const double*>(N);
-      const double inv = h[3];
-      node_header(nodes + (size_t)slot * PT_NODE_WORDS, h[0] + (double)(sub & 7u) / inv, h[1] + (double)((sub >> 3) & 7u) / inv,
-                  h[2] + (double)(sub >> 6) / inv, inv * 8.0, s, e);
+      const double inv = h[3], w = h[4];
+      node_header(nodes + (size_t)slot * PT_NODE_WORDS, h[0] + (double)(sub & 7u) * w, h[1] + (double)((sub >> 3) & 7u) * w,
+                  h[2] + (double)(sub >> 6) * w, inv * 8.0, s, e);
       id = slot + 1;
     }
   }

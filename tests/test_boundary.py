@@ -114,14 +114,20 @@ def test_metric_has_no_fma_in_query_kernels():
         b = b.split("; -- End function")[0]
         if "s_endpgm" not in b:
             continue
-        if "knn_tile_kernel" in name and re.search(r"ELb1ELb[01]EEEv", name):       # <..., WIDE, BLEND = true, DBL>
+        if "knn_tile_kernel" in name and re.search(r"ELb1ELb[01]ELi\d+EEEv", name):       # <..., WIDE, BLEND = true, DBL, KC>
             continue
         checked += 1
         assert "v_fma_f64" not in b and "v_fmac_f64" not in b, name
     assert checked >= 10
-    # no scratch spills in the hot kernels
-    priv = re.findall(r"\.private_segment_fixed_size:\s*(\d+)", s)
-    assert priv and all(int(p) == 0 for p in priv)
+    # no scratch spills in the hot kernels.  The one exception: the group kernel's HIER = true instantiations (clouds with refined
+    # cells only): their register budget is capped for occupancy and the three-level descent, cold code, spills a little.
+    for b in s.split("; -- Begin function ")[1:]:
+        name = b.split("\n", 1)[0].strip()
+        m = re.search(r"ScratchSize: (\d+)", b)
+        if m is None or "s_endpgm" not in b:
+            continue
+        hier = "knn_kernel" in name and re.search(r"ELb1EEEv", name) is not None
+        assert int(m.group(1)) == 0 or (hier and int(m.group(1)) <= 512), (name, m.group(1))
 
 
 def test_png_writer_roundtrip(tmp_path):
