@@ -170,11 +170,12 @@ int main(int argc, char** argv) {
   pt_set_param(ctx, "k_hint", (double)K);
   ply::CloudSoA cloud;
   std::vector<void*> pinned;
-  auto free_pinned = [&]() { for (void* q : pinned) pt_host_free(q); pinned.clear(); };
+  const bool pageable = std::getenv("PT_CLI_PAGEABLE") != nullptr;      // (measurement switch: plain malloc instead of page-locked memory)
+  auto free_pinned = [&]() { for (void* q : pinned) { if (pageable) std::free(q); else pt_host_free(q); } pinned.clear(); };
   long point_count = 0;
   std::atomic<int> upload_rc{PT_OK};
   const bool opened = ply::read_cloud_soa(
-      pc_file_name, cloud, point_count, [&](size_t bytes) { void* q = pt_host_alloc(bytes); if (q) pinned.push_back(q); return q; },
+      pc_file_name, cloud, point_count, [&](size_t bytes) { void* q = pageable ? std::malloc(bytes ? bytes : 1) : pt_host_alloc(bytes); if (q) pinned.push_back(q); return q; },
       [&](uint64_t n) { return pt_upload_begin(ctx, n, PT_F64, 1) == PT_OK; },
       [&](uint64_t first, uint64_t count) {
         const int r = pt_upload_range(ctx, first, count, cloud.x + first, cloud.y + first, cloud.z + first, cloud.rgb + 3 * first, cloud.nrm + 3 * first);
