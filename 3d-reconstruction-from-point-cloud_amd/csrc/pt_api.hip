@@ -67,6 +67,10 @@ struct pt_ctx {
   DevBuf x_xyz;                // transient targets of pt_query_soa / _aos / _bounded_dev (resident targets stay untouched)
   bool t_has_gidx = false;
   // refinement of heavy cells (pt_refine.hip): sub-grids inside cells with more than refine_threshold points
+  int refine_macros = PT_MAXBINS;       // finest grid the occupancy-driven refinement of h may ask for, in macro blocks (measured on the clustered
+                                        // generator: beyond 1024 the extra sort pass costs more than the shorter scans save)
+  int wave_force = 0;                   // 1: the heavy / light split also on clouds without density contrast (tests, tuning)
+  uint32_t wave_min = 512;              // targets with at least this many points in their 27 nearest cells get a wave each (0: never)
   double refine_threshold = 2048.0;     // 0: never refine.  Measured on the clustered generator (tools/probe_clustered.py): descending into a
                                         // sub-grid beats scanning the cell end to end from a few thousand points up -- 1B / 50M / k = 32: 3.16 s
                                         // unrefined, 2.23 s at 512, 2.12 s at 2048; 100M / 5M / k = 8: 34.1 / 42.1 / 35.8 / 37.7 ms at 0 / 512 / 2048 / 8192
@@ -87,7 +91,7 @@ struct pt_ctx {
   DevBuf ttb_mem;
 
   // scratch
-  DevBuf bbox6, counter, q_idx, q_d2, b_rgb, b_nrm, aos_stage, misc, bounds, todo, retry;
+  DevBuf bbox6, counter, q_idx, q_d2, b_rgb, b_nrm, aos_stage, misc, bounds, todo, retry, heavy;
   uint64_t* h_bbox = nullptr;   // pinned
   uint32_t* h_counter = nullptr;
 
@@ -147,10 +151,13 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
   const size_t small = PT_MAXBINS + 8;
   const size_t words = small * 4 /*counts1,start1,cursor1,tile_first2*/ + 16 /*tile_first1, seg_start1*/ +
                        ((size_t)nblocks + 8) * 3 + ((size_t)nblocks / 2048 + 16);
-  const size_t nchunks = pt_sort_num_chunks(npoints, rec_size), nbins1 = nblocks / PT_MACRO_BLOCKS + 1;
+  const int gsh = pt_sort_group_shift(nblocks);                                            // > 0: three-level sort
+  const size_t nmac = nblocks / PT_MACRO_BLOCKS, ngrp = (nmac + ((size_t)1 << gsh) - 1) >> gsh, nmacP = ngrp << gsh;
+  const size_t nchunks = pt_sort_num_chunks(npoints, rec_size), nbins1 = ngrp + 1;
   const size_t chunk_words = nblocks > PT_MAXBINS ? (nchunks + 1) * nbins1 + (nchunks / 64 + 2) * nbins1 : 0;
-  const size_t bid_words = nblocks > PT_MAXBINS ? ((size_t)npoints + 3) / 2 + 2 : 0;      // u16 per point, two-level sorts only
-  RES(c, mem, (words + chunk_words + bid_words + 16) * sizeof(uint32_t));
+  const size_t bid_words = nblocks > PT_MAXBINS && !gsh ? ((size_t)npoints + 3) / 2 + 2 : 0;      // u16 per point, two-level sorts only
+  const size_t mac_words = gsh ? (nmacP + 8) * 4 : 0;
+  RES(c, mem, (words + chunk_words + bid_words + mac_words + 16) * sizeof(uint32_t));
   uint32_t* p = (uint32_t*)mem.p;
   tb.counts1 = p; p += small;
   tb.start1 = p; p += small;
@@ -165,6 +172,9 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
   tb.chunk_hist = p; p += (nchunks + 1) * nbins1;
   tb.chunk_gsum = p; p += (nchunks / 64 + 2) * nbins1;
   tb.bid = bid_words ? (uint16_t*)p : nullptr;
+  p += bid_words;
+  tb.countsM = tb.startM = tb.cursorM = tb.tile_firstM = nullptr;
+  if (gsh) { tb.countsM = p; p += nmacP + 8; tb.startM = p; p += nmacP + 8; tb.cursorM = p; p += nmacP + 8; tb.tile_firstM = p; p += nmacP + 8; }
   tb.occupied = nullptr;
   tb.shadow32 = nullptr;
   tb.status = nullptr;
@@ -198,8 +208,8 @@ void choose_grid(pt_ctx* c, const double mn[3], const double mx[3], double force
     }
     g.inv_h = inv_h;
     g.h = h;
-    if (nmacro <= PT_MAXBINS) { g.nblocks = (int)(nmacro * PT_MACRO_BLOCKS); break; }
-    h *= 1.2599210498948732;   // too many macro blocks for one partition pass: double the cell volume
+    if (nmacro <= (uint64_t)(force_h > 0 ? c->refine_macros : PT_MAX_MACROS)) { g.nblocks = (int)(nmacro * PT_MACRO_BLOCKS); break; }
+    h *= 1.2599210498948732;   // too many macro blocks for the sort (and a cell table beyond 2^31 entries): double the cell volume
   }
 }
 
@@ -379,7 +389,7 @@ int rebuild(pt_ctx* c) {
   c->st.grid_dim[0] = c->gp.dim[0]; c->st.grid_dim[1] = c->gp.dim[1]; c->st.grid_dim[2] = c->gp.dim[2];
   c->st.cell_size = c->gp.h;
   c->st.n_cells = ncells;
-  c->st.n_levels = nblocks <= PT_MAXBINS ? 1 : 2;
+  c->st.n_levels = nblocks <= PT_MAXBINS ? 1 : (pt_sort_group_shift(nblocks) ? 3 : 2);
   (void)ncells;
   const uint64_t s = tsize(c->src_type) * 3;
   c->st.bytes_alg_build = c->n * (2 * s + 4);
@@ -470,13 +480,51 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
   // what the tile kernel does not take (or leaves over) goes to the 8-lanes-per-target kernel: the plain one, or -- when the build
   // refined heavy cells -- the one that descends into their sub-grids instead of scanning them end to end
   const bool hier = c->n_nodes > 0;
+  // Clouds with strong density contrast: targets whose 27 nearest cells hold many points (wave_min or more) are listed by the group
+  // kernel instead of being answered, and get ONE WAVE EACH afterwards (knn_wave_kernel); one read-back of the list length.
+  const bool wave = c->wave_min > 0 && (contrast || hier || c->st.n_refine > 0 || c->wave_force) && m && k <= 64;
+  // buffers of the split: marks (one byte per target), the two ordered lists (m words together), per-tile offsets and scan scratch
+  const uint32_t mtiles = pt_mark_tiles(m);
+  uint8_t* heavy = nullptr;
+  uint32_t *hlist = nullptr, *hoff1 = nullptr, *hoff2 = nullptr, *hscan = nullptr, *hcnt = (uint32_t*)c->counter.p + 12;
+  if (wave) {
+    RES(c, c->heavy, (size_t)m * sizeof(uint32_t) + (((size_t)m + 15) & ~(size_t)15) + ((size_t)mtiles + 4) * 3 * sizeof(uint32_t) + 64);
+    hlist = (uint32_t*)c->heavy.p;
+    hoff1 = hlist + m; hoff2 = hoff1 + mtiles + 4; hscan = hoff2 + mtiles + 4;
+    heavy = (uint8_t*)(hscan + mtiles + 4);
+  }
+  c->st.n_wave = 0;
+  // marks -> ordered lists; one read-back of the two lengths.  false: a HIP call failed (the caller's hipGetLastError reports it)
+  auto wave_lists = [&]() -> bool {
+    pt_launch_mark_count(heavy, m, hoff1, hoff2, hscan, c->stream);
+    if (hipMemcpyAsync(c->h_counter + 12, hoff1 + mtiles, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(c->h_counter + 13, hoff2 + mtiles, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return false;
+    c->st.n_wave = c->h_counter[12] + c->h_counter[13];
+    if (!c->st.n_wave) return false;
+    pt_launch_mark_write(heavy, m, hoff1, hoff2, hlist, hlist + c->h_counter[12], c->stream);
+    return hipMemcpyAsync(hcnt, c->h_counter + 12, 8, hipMemcpyHostToDevice, c->stream) == hipSuccess;      // the kernels read their list length from the device
+  };
   auto group_f32 = [&](const RecF* tg, const double* bnd, const uint32_t* list, const uint32_t* list_n) {
-    if (hier) pt_launch_knn_hier<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const uint32_t*)c->cell_node.p, (const uint32_t*)c->nodes.p, (uint32_t)c->refine_threshold, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream);
-    else pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream);
+    if (wave) (void)hipMemsetAsync(heavy, 0, m, c->stream);
+    if (hier) pt_launch_knn_hier<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const uint32_t*)c->cell_node.p, (const uint32_t*)c->nodes.p, (uint32_t)c->refine_threshold, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream, heavy, c->wave_min);
+    else pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream, heavy, c->wave_min);
+    if (wave && wave_lists()) {                             // plain variant for the first list, descending variant for the second
+      pt_launch_knn_wave<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, nullptr, nullptr, 0xFFFFFFFFu, tg, c->h_counter[12], k, bnd, idx_dev, d2_dev,
+                               hlist, hcnt, c->stream);
+      pt_launch_knn_wave<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const uint32_t*)c->cell_node.p, (const uint32_t*)c->nodes.p, (uint32_t)c->refine_threshold,
+                               tg, c->h_counter[13], k, bnd, idx_dev, d2_dev, hlist + c->h_counter[12], hcnt + 1, c->stream);
+    }
   };
   auto group_f64 = [&](const RecD* tg, const double* bnd, const uint32_t* list, const uint32_t* list_n) {
-    if (hier) pt_launch_knn_hier<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, (const uint32_t*)c->cell_node.p, (const uint32_t*)c->nodes.p, (uint32_t)c->refine_threshold, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream);
-    else pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream);
+    if (wave) (void)hipMemsetAsync(heavy, 0, m, c->stream);
+    if (hier) pt_launch_knn_hier<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, (const uint32_t*)c->cell_node.p, (const uint32_t*)c->nodes.p, (uint32_t)c->refine_threshold, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream, heavy, c->wave_min);
+    else pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream, heavy, c->wave_min);
+    if (wave && wave_lists()) {
+      pt_launch_knn_wave<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, nullptr, nullptr, 0xFFFFFFFFu, tg, c->h_counter[12], k, bnd, idx_dev, d2_dev,
+                               hlist, hcnt, c->stream);
+      pt_launch_knn_wave<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, (const uint32_t*)c->cell_node.p, (const uint32_t*)c->nodes.p, (uint32_t)c->refine_threshold,
+                               tg, c->h_counter[13], k, bnd, idx_dev, d2_dev, hlist + c->h_counter[12], hcnt + 1, c->stream);
+    }
   };
   if (ttype == PT_F32) {
     const float* x = (const float*)txyz;
@@ -604,7 +652,7 @@ void pt_ctx_destroy(pt_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in_xyz, &c->in_gidx, &c->attr, &c->rec, &c->rec_tmp, &c->cell_start, &c->stb_mem, &c->t_xyz, &c->t_gidx, &c->trec,
                    &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr, &c->retry, &c->rec32, &c->up_rgb, &c->up_nrm, &c->x_bounds, &c->x_counts, &c->x_matrix, &c->x_off, &c->x_req, &c->x_row, &c->x_rreq,
-                   &c->x_rxyz, &c->x_rbound, &c->x_ans_i, &c->x_ans_d, &c->x_back_i, &c->x_back_d, &c->x_flags, &c->x_rows, &c->cell_node, &c->nodes};
+                   &c->x_rxyz, &c->x_rbound, &c->x_ans_i, &c->x_ans_d, &c->x_back_i, &c->x_back_d, &c->x_flags, &c->x_rows, &c->cell_node, &c->nodes, &c->heavy};
   for (DevBuf* b : all) release(c, *b);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);
@@ -625,7 +673,7 @@ int pt_set_stream(pt_ctx* c, void* hip_stream) {
 
 int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!c || !name) return PT_ERR_ARG;
-  if (!strcmp(name, "rho")) { if (!(value >= 0.25 && value <= 4096)) return fail(c, PT_ERR_ARG, "rho out of range"); c->rho = value; return PT_OK; }
+  if (!strcmp(name, "rho")) { if (!(value >= 1e-4 && value <= 4096)) return fail(c, PT_ERR_ARG, "rho out of range"); c->rho = value; return PT_OK; }
   if (!strcmp(name, "k_hint")) {
     // cell density for the k the caller is going to ask for: ring 1 (3x3x3 cells) must usually contain the k nearest
     // (expected k-th distance ~0.8 cell sides), and a 10^3-cell region must fit the tile kernel's LDS budget
@@ -638,6 +686,9 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!strcmp(name, "sync")) { c->sync = value != 0; return PT_OK; }
   if (!strcmp(name, "adaptive")) { c->adaptive = value != 0; return PT_OK; }
   if (!strcmp(name, "tile")) { c->tile = (int)value; return PT_OK; }
+  if (!strcmp(name, "refine_macros")) { if (!(value >= 1 && value <= PT_MAX_MACROS)) return fail(c, PT_ERR_ARG, "refine_macros out of range"); c->refine_macros = (int)value; return PT_OK; }
+  if (!strcmp(name, "wave_force")) { c->wave_force = value != 0; return PT_OK; }
+  if (!strcmp(name, "wave_min")) { if (!(value >= 0 && value <= 4e9)) return fail(c, PT_ERR_ARG, "wave_min out of range"); c->wave_min = (uint32_t)value; return PT_OK; }
   if (!strcmp(name, "refine_threshold")) { if (!(value >= 0 && value <= 1e9)) return fail(c, PT_ERR_ARG, "refine_threshold out of range"); c->refine_threshold = value; return PT_OK; }
   if (!strcmp(name, "guess_min_points")) { c->guess_min_points = value < 1 ? 1 : (uint64_t)value; return PT_OK; }   // sampled-bbox builds from this size up   // 0 group kernel only, 1 auto, 2 small tiles, 3 large tiles
   if (!strcmp(name, "own_stream")) { if (value != 0) c->stream = c->own_stream; return PT_OK; }

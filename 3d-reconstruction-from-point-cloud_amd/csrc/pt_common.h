@@ -19,12 +19,15 @@
 #define PT_BLOCK_CELLS 512          // 8 x 8 x 8 cells per block
 #define PT_MACRO_BLOCKS 512         // 8 x 8 x 8 blocks per macro block
 #define PT_MAXBINS 1024             // LDS histogram bins per partition pass (macro blocks, or blocks when <= 1024)
+#define PT_MAX_MACROS 8192          // macro blocks of the largest grid: beyond PT_MAXBINS of them the sort takes a pass more (groups of macro blocks first)
 #define PT_CELL_EPS 1e-9            // slack (in cell units) on every cell-box bound: cell membership is
                                     // computed in fp64 with ~1e-12 cell units of rounding at most
 
 // refined ("heavy") cells, pt_refine.hip: one node = header {origin x, y, z in level-0 cell units, sub-cells per cell unit, sub-cell
-// side in cell units} as five doubles, 513 absolute starts of its 8 x 8 x 8 sub-cells (sub = sz << 6 | sy << 3 | sx), 512 child node ids (id + 1, 0 = leaf)
-#define PT_NODE_START 10
+// side in cell units} as five doubles, the 64-bit mask of the non-empty rows (bit sz * 8 + sy) as two words, 513 absolute starts of its
+// 8 x 8 x 8 sub-cells (sub = sz << 6 | sy << 3 | sx), 512 child node ids (id + 1, 0 = leaf)
+#define PT_NODE_ROWMASK 10
+#define PT_NODE_START 12
 #define PT_NODE_CHILD (PT_NODE_START + 513)
 #define PT_NODE_WORDS 1040
 #define PT_REFINE_DEPTH 3           // levels below the grid: sub-cells of 1/8, 1/64, 1/512 of a cell side

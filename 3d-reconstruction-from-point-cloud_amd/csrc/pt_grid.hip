@@ -50,11 +50,12 @@ struct RecLoader {
 struct BinSpec {
   int mode;    // 0: local bin = blk >> shift, global bin = local      (pass 1)
                // 1: local bin = blk & mask,   global bin = blk         (pass 2; seg = blk >> shift)
+               // 2: local bin = macro & mask, global bin = macro       (middle pass of a three-level sort; macro = blk >> 9, seg = macro >> shift)
   int shift;
   int nbins;   // local bins (<= PT_MAXBINS)
 };
 __device__ inline uint32_t local_bin(const BinSpec& b, uint32_t blk) {
-  return b.mode == 0 ? (blk >> b.shift) : (blk & ((1u << b.shift) - 1u));
+  return b.mode == 0 ? (blk >> b.shift) : ((b.mode == 1 ? blk : blk >> 9) & ((1u << b.shift) - 1u));
 }
 __device__ inline uint32_t global_bin(const BinSpec& b, uint32_t seg, uint32_t local) {
   return b.mode == 0 ? local : ((seg << b.shift) + local);
@@ -165,6 +166,36 @@ __global__ __launch_bounds__(WG) void seg_setup_kernel(const uint32_t* __restric
     ec += c[i]; et += t[i];
   }
   if (threadIdx.x == 0) { start[nseg] = n; tile_first[nseg] = tot; }
+}
+
+// the same for any number of segments (three-level sorts: the macro blocks), one workgroup walking them 1024 at a time
+__global__ __launch_bounds__(WG) void seg_setup_big_kernel(const uint32_t* __restrict__ counts, int nseg, uint32_t n, uint32_t tile_pts,
+                                                           uint32_t* start, uint32_t* cursor, uint32_t* tile_first) {
+  __shared__ uint32_t wsum[4];
+  uint32_t basec = 0, baset = 0;
+  for (int b0 = 0; b0 < nseg; b0 += WG * 4) {
+    uint32_t c[4], t[4], sc = 0, st = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = b0 + threadIdx.x * 4 + i;
+      c[i] = b < nseg ? counts[b] : 0u;
+      t[i] = (c[i] + tile_pts - 1) / tile_pts;
+      sc += c[i]; st += t[i];
+    }
+    uint32_t totc, tott;
+    uint32_t ec = basec + block_excl_scan(sc, wsum, totc);
+    __syncthreads();
+    uint32_t et = baset + block_excl_scan(st, wsum, tott);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = b0 + threadIdx.x * 4 + i;
+      if (b < nseg) { start[b] = ec; cursor[b] = ec; tile_first[b] = et; }
+      ec += c[i]; et += t[i];
+    }
+    basec += totc; baset += tott;
+  }
+  if (threadIdx.x == 0) { start[nseg] = n; tile_first[nseg] = baset; }
 }
 
 // ---- generic exclusive scan of u32 ---------------------------------------------------------------
@@ -419,7 +450,7 @@ __global__ __launch_bounds__(SW) void scatter_chunk_kernel(Loader in, typename L
         const uint32_t blk = block_of_rec(gp, v);
         const uint32_t pos = binB[local_bin(bs, blk)] + slot;
         out[pos] = v;
-        bid[pos] = (uint16_t)(blk & (PT_MACRO_BLOCKS - 1));   // 2 bytes here save pass 2's histogram a 16-byte read
+        if (bid) bid[pos] = (uint16_t)(blk & (PT_MACRO_BLOCKS - 1));   // 2 bytes here save pass 2's histogram a 16-byte read
       }
     }
     __syncthreads();
@@ -677,9 +708,55 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
     mark(5);
     return done(do_finalize ? out_final : tmp);
   }
+  const BinSpec b2{1, 9, PT_MACRO_BLOCKS};
+  if (const int gsh = pt_sort_group_shift(nblocks)) {
+    // three levels (more than PT_MAXBINS macro blocks: fine grids over clouds with strong density contrast):
+    // planar -> tmp (by GROUP of 2^gsh macro blocks) -> out_final (by macro block) -> tmp (by block) -> out_final (by cell).
+    // The two later passes take their histograms from the records themselves (no 2-byte ids beside them).
+    const uint32_t ngrp = (nmacro + (1u << gsh) - 1u) >> gsh, nmacP = ngrp << gsh;
+    const BinSpec bg{0, 9 + gsh, (int)ngrp}, bm{2, gsh, 1 << gsh};
+    const int chunk_tiles = pt_sort_chunk_tiles(n, sizeof(Rec));
+    const uint32_t nchunks = n ? (ntiles + chunk_tiles - 1) / chunk_tiles : 0;
+    const uint32_t ngroups = (nchunks + COL_GROUP - 1) / COL_GROUP;
+    const int tpw = 4;
+    ck(hipMemsetAsync(tb.counts1, 0, sizeof(uint32_t) * (PT_MAXBINS + 1), s));
+    ck(hipMemsetAsync(tb.countsM, 0, sizeof(uint32_t) * ((size_t)nmacP + 1), s));
+    if (n) {
+      hipLaunchKernelGGL((hist_chunk_kernel<PlanarLoader<T>, ITEMS>), dim3(nchunks), dim3(WG), 0, s, pl, gp, bg, n, chunk_tiles, tb.chunk_hist, bbox6_verify);
+      hipLaunchKernelGGL(colsum_kernel, dim3(ngroups), dim3(WG), 0, s, tb.chunk_hist, (int)nchunks, (int)ngrp, tb.chunk_gsum);
+      hipLaunchKernelGGL(colscan_kernel, dim3(1), dim3(WG), 0, s, tb.chunk_gsum, (int)ngroups, (int)ngrp, tb.counts1);
+    }
+    hipLaunchKernelGGL(seg_setup_kernel, dim3(1), dim3(WG), 0, s, tb.counts1, (int)ngrp, n, TILE, tb.start1, tb.cursor1, tb.tile_first2);
+    mark(1);
+    if (n) {
+      hipLaunchKernelGGL(colapply_kernel, dim3(ngroups), dim3(WG), 0, s, tb.chunk_hist, (int)nchunks, (int)ngrp, tb.chunk_gsum, tb.start1);
+      if (chunk_tiles % 2 == 0)
+        hipLaunchKernelGGL((scatter_chunk_kernel<PlanarLoader<T>, ITEMS_S, 2 * SW>), dim3(nchunks), dim3(2 * SW), 0, s, pl, tmp, gp, bg, n, chunk_tiles / 2, tb.chunk_hist,
+                           (uint16_t*)nullptr);
+      else
+        hipLaunchKernelGGL((scatter_chunk_kernel<PlanarLoader<T>, ITEMS_S, SW>), dim3(nchunks), dim3(SW), 0, s, pl, tmp, gp, bg, n, chunk_tiles, tb.chunk_hist,
+                           (uint16_t*)nullptr);
+    }
+    mark(2);
+    RecLoader<Rec> rg{tmp};
+    const uint32_t ntilesG = ntiles + ngrp;
+    if (n) hipLaunchKernelGGL((hist_kernel<RecLoader<Rec>, ITEMS>), dim3((ntilesG + tpw - 1) / tpw), dim3(WG), 0, s, rg, gp, bm, tb.start1, tb.tile_first2, (int)ngrp, tb.countsM, tpw);
+    hipLaunchKernelGGL(seg_setup_big_kernel, dim3(1), dim3(WG), 0, s, tb.countsM, (int)nmacP, n, TILE, tb.startM, tb.cursorM, tb.tile_firstM);
+    if (n) hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS_S, SW>), dim3(ntilesG), dim3(SW), 0, s, rg, out_final, gp, bm, tb.start1, tb.tile_first2, (int)ngrp, tb.cursorM);
+    RecLoader<Rec> rm{out_final};
+    const uint32_t ntilesM = ntiles + nmacP;
+    if (n) hipLaunchKernelGGL((hist_kernel<RecLoader<Rec>, ITEMS>), dim3((ntilesM + tpw - 1) / tpw), dim3(WG), 0, s, rm, gp, b2, tb.startM, tb.tile_firstM, (int)nmacP, tb.block_count, tpw);
+    pt_launch_scan_u32(tb.block_count, tb.block_start, nblocks + 1, tb.scan_tmp, s);
+    ck(hipMemcpyAsync(tb.cursor2, tb.block_start, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s));
+    mark(3);
+    if (n) hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS_S, SW>), dim3(ntilesM), dim3(SW), 0, s, rm, tmp, gp, b2, tb.startM, tb.tile_firstM, (int)nmacP, tb.cursor2);
+    mark(4);
+    if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start, tb.occupied, tb.shadow32);
+    mark(5);
+    return done(do_finalize ? out_final : tmp);
+  }
   // two levels: planar -> out_final (by macro block) -> tmp (by block) -> out_final (by cell)
   const BinSpec b1{0, 9, (int)nmacro};
-  const BinSpec b2{1, 9, PT_MACRO_BLOCKS};
   const int chunk_tiles = pt_sort_chunk_tiles(n, sizeof(Rec));
   const uint32_t nchunks = n ? (ntiles + chunk_tiles - 1) / chunk_tiles : 0;
   const uint32_t ngroups = (nchunks + COL_GROUP - 1) / COL_GROUP;

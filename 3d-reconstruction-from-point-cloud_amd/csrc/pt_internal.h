@@ -21,6 +21,10 @@ struct SortTables {
   uint32_t* occupied;    // optional [nblocks]: non-empty cells of every block | points of its fullest cell << 10, written by finalize (may alias block_count)
   RecF* shadow32;        // optional [npoints] (fp64 clouds): fp32-rounded copy of the sorted records, id = sorted position (tile kernel's LDS image)
   uint16_t* bid;         // [npoints] (two-level sorts): block-in-macro of every record as pass 1 placed it -- what pass 2's histogram reads
+  uint32_t* countsM;     // three-level sorts (more than PT_MAXBINS macro blocks) only: [macros+1] histogram of the macro blocks, its scan,
+  uint32_t* startM;      //   the scatter cursors and the tile table of the last partition pass (segments = macro blocks)
+  uint32_t* cursorM;
+  uint32_t* tile_firstM;
   hipError_t* status;    // optional: receives the first HIP error of the sort's launch path (hipSuccess otherwise)
   hipEvent_t* ev;        // optional [6]: start, after hist1, scatter1, hist2+scan, scatter2, finalize (null = no timing)
 };
@@ -42,6 +46,13 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
                                uint64_t* bbox6_verify = nullptr);   // two-level sorts: pass 1's histogram also reduces the exact bbox into it
 void pt_launch_sum_u32(const uint32_t* v, uint32_t n, uint32_t* out, hipStream_t s);   // finalize's block words: out[0] += non-empty cells, out[1] = max(fullest cell)
 int pt_sort_tile_points(size_t rec_size);
+// grids of more than PT_MAXBINS macro blocks: pass 1 partitions by GROUPS of 2^shift macro blocks (at most PT_MAXBINS groups)
+inline int pt_sort_group_shift(uint32_t nblocks) {
+  const uint32_t nm = nblocks / PT_MACRO_BLOCKS;
+  int sh = 0;
+  while (((nm + (1u << sh) - 1u) >> sh) > (uint32_t)PT_MAXBINS) ++sh;
+  return sh;
+}
 int pt_sort_chunk_tiles(uint32_t n, size_t rec_size);
 uint32_t pt_sort_num_chunks(uint32_t n, size_t rec_size);
 
@@ -53,7 +64,13 @@ void pt_launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t*
 // the target's id.  Results go to out_idx/out_d2 at row `id` (k entries per row).
 template <class Rec>
 void pt_launch_knn(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const Rec* tgt, uint32_t m, int k,
-                   const double* bound2, uint32_t* out_idx, double* out_d2, const uint32_t* list, const uint32_t* list_n, hipStream_t s);
+                   const double* bound2, uint32_t* out_idx, double* out_d2, const uint32_t* list, const uint32_t* list_n, hipStream_t s,
+                   uint8_t* heavy = nullptr, uint32_t wave_min = 0);
+// (heavy != null, one zeroed byte per target position: targets whose 27 nearest cells hold >= wave_min points are MARKED instead of
+//  being answered -- 1, or 2 when one of those cells is refined; pt_launch_mark_count / _write turn the marks into ordered lists)
+void pt_launch_mark_count(const uint8_t* mark, uint32_t m, uint32_t* off1, uint32_t* off2, uint32_t* scan_tmp, hipStream_t s);   // off*: [tiles + 1], totals last
+void pt_launch_mark_write(const uint8_t* mark, uint32_t m, const uint32_t* off1, const uint32_t* off2, uint32_t* list1, uint32_t* list2, hipStream_t s);
+uint32_t pt_mark_tiles(uint32_t m);
 // quad-per-target LDS tile kernel (fp32 records, k <= 32); leftovers go to todo[*todo_n] and are finished by pt_launch_knn(list=todo)
 // staged-region capacities (records) of the tile kernel's geometries: what is left of 80 KB (two workgroups per CU) or
 // 160 KB (one) after the per-lane queue segments and the cell table
@@ -144,4 +161,10 @@ void pt_launch_reshadow(const RecD* rec, uint32_t n, RecF* shadow, hipStream_t s
 template <class Rec>
 void pt_launch_knn_hier(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const uint32_t* cell_node, const uint32_t* nodes, uint32_t node_thr,
                         const Rec* tgt, uint32_t m, int k, const double* bound2, uint32_t* out_idx, double* out_d2, const uint32_t* list,
+                        const uint32_t* list_n, hipStream_t s, uint8_t* heavy = nullptr, uint32_t wave_min = 0);
+// one wave per target (dense neighbourhoods, k <= 64): the targets at positions list[0 .. count) of the sorted target array, or the
+// first `count` targets when list is null (list_n, if given, holds the live count on the device); cell_node / nodes may be null
+template <class Rec>
+void pt_launch_knn_wave(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const uint32_t* cell_node, const uint32_t* nodes, uint32_t node_thr,
+                        const Rec* tgt, uint32_t count, int k, const double* bound2, uint32_t* out_idx, double* out_d2, const uint32_t* list,
                         const uint32_t* list_n, hipStream_t s);

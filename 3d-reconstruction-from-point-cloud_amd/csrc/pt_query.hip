@@ -73,6 +73,9 @@ struct TopList {
   int L, hl, hr;
   uint32_t notfirst;       // 0 for lane 0 of the group, 1 otherwise
   bool fullk;              // k == 8*KPL: the rank k-1 entry is the last entry of lane 7
+#ifdef PT_VISITS
+  uint32_t nv;             // instrumented build (tools/probe_visits.py): offers made (8 records each)
+#endif
 
   __device__ void init(int lane_in_group, int k, double bound) {
 #pragma unroll
@@ -85,6 +88,9 @@ struct TopList {
     bnd_d = bound;
     lim_d = bound;
     lim_i = PT_NOIDX_U;
+#ifdef PT_VISITS
+    nv = 0;
+#endif
   }
   // cheap pre-test against the cached limit (may be stale, i.e. too permissive -- never too strict)
   __device__ bool may_accept(double d, uint32_t i) const { return key_lt(d, i, lim_d, lim_i); }
@@ -138,6 +144,9 @@ struct TopList {
 
   // offer one candidate per lane (d = +inf / id = NOIDX for lanes without one)
   __device__ void offer(double d, uint32_t id, int gshift) {
+#ifdef PT_VISITS
+    ++nv;
+#endif
     const bool pass = may_accept(d, id) && !(d > bnd_d);
     uint32_t mask = (uint32_t)(__ballot(pass) >> gshift) & 0xFFu;
     if (mask) {
@@ -210,48 +219,59 @@ struct HierScan {
     const double rx = (T.u[0] - ox) * inv, ry = (T.u[1] - oy) * inv, rz = (T.u[2] - oz) * inv;
     const bool inside = rx >= 0.0 && rx < 8.0 && ry >= 0.0 && ry < 8.0 && rz >= 0.0 && rz < 8.0;
     const uint32_t own = inside ? (uint32_t)(((int)rz << 6) | ((int)ry << 3) | (int)rx) : 0xFFFFFFFFu;
-    // Sweep: step -1 is the target's own sub-cell alone (so that the bound is tight before anything else is looked at), steps
-    // 0..7 are the 64 rows (sy, sz) of eight sub-cells, eight rows per step, one lane testing each; the own sub-cell is skipped
-    // when its row comes by.  One code path serves both, so that the scan and the descent are instantiated once per level.
-    for (int step = inside ? -1 : 0; step < 64 / GL; ++step) {
-      uint32_t mask = 1u;
-      if (step >= 0) {
-        const int row = step * GL + top.L, sy = row & 7, sz = row >> 3;
-        const double s2 = gap2(1, oy + (double)sy * w, oy + (double)(sy + 1) * w) + gap2(2, oz + (double)sz * w, oz + (double)(sz + 1) * w);
-        const bool live = !(s2 * T.h2 > top.lim_d) && N[PT_NODE_START + row * 8] != N[PT_NODE_START + row * 8 + 8];     // (and not empty)
-        mask = (uint32_t)((__ballot(live) >> gshift) & 0xFFull);
+    // per-axis gaps of the eight slabs of sub-cells, one per lane: every box test below is two or three shuffles and adds
+    const double fl = (double)top.L;
+    const double gxl = gap2(0, ox + fl * w, ox + (fl + 1.0) * w), gyl = gap2(1, oy + fl * w, oy + (fl + 1.0) * w), gzl = gap2(2, oz + fl * w, oz + (fl + 1.0) * w);
+    // the rows (sy, sz) that can hold anything under the bound as it is now -- geometry only, no memory touched; lane L tests
+    // the rows with sy = L, one sz per step
+    uint32_t live_lo = 0, live_hi = 0;                     // bit sz * 8 + sy, group-uniform
+#pragma unroll
+    for (int sz = 0; sz < 8; ++sz) {
+      const bool ok = !((gyl + __shfl(gzl, sz, GL)) * T.h2 > top.lim_d);
+      const uint32_t m8 = (uint32_t)((__ballot(ok) >> gshift) & 0xFFull);
+      if (sz < 4) live_lo |= m8 << (8 * sz); else live_hi |= m8 << (8 * (sz - 4));
+    }
+    live_lo &= N[PT_NODE_ROWMASK];                         // ... and are not empty (the node's row mask, next to its header)
+    live_hi &= N[PT_NODE_ROWMASK + 1];
+    // Sweep: first the target's own sub-cell alone (so that the bound is tight before anything else is looked at), then the live
+    // rows of eight sub-cells; the own sub-cell is skipped when its row comes by.  One code path serves both, so that the scan and
+    // the descent are instantiated once per level.  A row's nine starts and eight child links are fetched by the eight lanes in
+    // ONE go (a single memory latency per row) and handed round by shuffles.
+    bool first = inside;
+    while (first || (live_lo | live_hi)) {                  // group-uniform
+      int r2, xa, xb;
+      if (first) { r2 = (int)(own >> 3); xa = xb = (int)(own & 7u); }
+      else {
+        if (live_lo) { r2 = __ffs((int)live_lo) - 1; live_lo &= live_lo - 1; }
+        else { r2 = 32 + __ffs((int)live_hi) - 1; live_hi &= live_hi - 1; }
+        const double t2 = __shfl(gyl, r2 & 7, GL) + __shfl(gzl, r2 >> 3, GL);
+        if (t2 * T.h2 > top.lim_d) continue;                // the bound may have tightened since the ballots
+        xa = 0; xb = 7;
+        while (xa <= xb && (__shfl(gxl, xa, GL) + t2) * T.h2 > top.lim_d) ++xa;
+        while (xb >= xa && (__shfl(gxl, xb, GL) + t2) * T.h2 > top.lim_d) --xb;
+        if (xa > xb) continue;
       }
-      while (mask) {                                        // group-uniform
-        const int j = __ffs((int)mask) - 1;
-        mask &= mask - 1;
-        int r2, xa, xb;
-        if (step < 0) { r2 = (int)(own >> 3); xa = xb = (int)(own & 7u); }
-        else {
-          r2 = step * GL + j;
-          const int y2 = r2 & 7, z2 = r2 >> 3;
-          const double t2 = gap2(1, oy + (double)y2 * w, oy + (double)(y2 + 1) * w) + gap2(2, oz + (double)z2 * w, oz + (double)(z2 + 1) * w);
-          if (t2 * T.h2 > top.lim_d) continue;              // the bound may have tightened since the ballot
-          xa = 0; xb = 7;
-          while (xa <= xb && (gap2(0, ox + (double)xa * w, ox + (double)(xa + 1) * w) + t2) * T.h2 > top.lim_d) ++xa;
-          while (xb >= xa && (gap2(0, ox + (double)xb * w, ox + (double)(xb + 1) * w) + t2) * T.h2 > top.lim_d) --xb;
+      const bool sweep = !first;
+      first = false;
+      const uint32_t stl = N[PT_NODE_START + r2 * 8 + top.L], end8 = N[PT_NODE_START + r2 * 8 + 8];
+      uint32_t chl = 0;
+      if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) chl = N[PT_NODE_CHILD + r2 * 8 + top.L];
+      // leaf sub-cells next to each other are one contiguous run of records, scanned in one go; a sub-cell that is a node, the
+      // own sub-cell (already done) and the end of the row cut the run
+      uint32_t run_s = 0, run_e = 0;
+      for (int x = xa; x <= xb + 1; ++x) {
+        const uint32_t sub = (uint32_t)(r2 * 8 + x);
+        uint32_t child = 0;
+        bool cut = x > xb || (sweep && sub == own);
+        if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) { if (!cut) { child = (uint32_t)__shfl((int)chl, x, GL); cut = child != 0u; } }
+        if (!cut) {
+          if (run_e == run_s) run_s = (uint32_t)__shfl((int)stl, x, GL);
+          run_e = x < 7 ? (uint32_t)__shfl((int)stl, x + 1, GL) : end8;
+          continue;
         }
-        // leaf sub-cells next to each other are one contiguous run of records, scanned in one go; a sub-cell that is a node, the
-        // own sub-cell (already done) and the end of the row cut the run
-        uint32_t run_s = 0, run_e = 0;
-        for (int x = xa; x <= xb + 1; ++x) {
-          const uint32_t sub = (uint32_t)(r2 * 8 + x);
-          uint32_t child = 0;
-          bool cut = x > xb || (step >= 0 && sub == own);
-          if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) { if (!cut) { child = N[PT_NODE_CHILD + sub]; cut = child != 0u; } }
-          if (!cut) {
-            if (run_e == run_s) run_s = N[PT_NODE_START + sub];
-            run_e = N[PT_NODE_START + sub + 1];
-            continue;
-          }
-          if (run_e > run_s) range(run_s, run_e);
-          run_s = run_e = 0;
-          if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) { if (child) node<DEPTH + 1>(child); }
-        }
+        if (run_e > run_s) range(run_s, run_e);
+        run_s = run_e = 0;
+        if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) { if (child) node<DEPTH + 1>(child); }
       }
     }
   }
@@ -295,19 +315,19 @@ __device__ void scan_row_generic(const GridParams& gp, const Rec* __restrict__ s
         const uint32_t s1 = cs[key + (uint32_t)i], e1 = cs[key + (uint32_t)i + 1u];
         const bool defer = pend->heavy(s1, e1) && pend->push(key + (uint32_t)i, top.L);
         if (!defer) { e = e1; continue; }
-        for (uint32_t base = s; base < e; base += GL) {       // flush the light run collected so far
-          const uint32_t p = base + top.L;
+        for (uint32_t base = s; base < e; base += GL) {
+          const uint32_t p = base + (uint32_t)top.L;
           double d = INFINITY;
           uint32_t id = PT_NOIDX_U;
           if (p < e) { const Rec r = src[p]; d = dist2(T.q, r); id = r.id; }
           top.offer(d, id, gshift);
-        }
+        }       // (the light run collected so far)
         s = e = e1;
       }
       (void)e_all;
     }
     for (uint32_t base = s; base < e; base += GL) {
-      const uint32_t p = base + top.L;
+      const uint32_t p = base + (uint32_t)top.L;
       double d = INFINITY;
       uint32_t id = PT_NOIDX_U;
       if (p < e) { const Rec r = src[p]; d = dist2(T.q, r); id = r.id; }
@@ -333,7 +353,10 @@ struct RowPlan {
 
 // HIER: the grid carries refined cells (pt_refine.hip: cell_node / nodes / node_thr).  Cells with more than node_thr points are then
 // left out of the flat scans, remembered in the group's pending list and descended into (HierScan) at the head of the ring loop.
-struct HierArgs { const uint32_t* cell_node; const uint32_t* nodes; uint32_t thr; };
+// heavy / heavy_n / wave_min: targets whose 27 nearest cells hold at least wave_min points are not answered here but listed (their
+// position in the sorted target array) for the wave kernel below -- one wave per target pays off where the scans are long.
+// heavy: one byte per target position, zeroed by the caller; 1 = wave kernel, 2 = its descending variant (a refined cell among the 27).
+struct HierArgs { const uint32_t* cell_node; const uint32_t* nodes; uint32_t thr; uint8_t* heavy; uint32_t wave_min; };
 template <class Rec, int KPL, bool HIER>
 __global__ __launch_bounds__(WG, HIER ? (KPL == 4 ? 3 : 4) : 1) void knn_kernel(GridParams gp, const Rec* __restrict__ src, const uint32_t* __restrict__ cs,
                                                  const Rec* __restrict__ tgt, uint32_t m, int k, const double* __restrict__ bound2,
@@ -346,6 +369,9 @@ __global__ __launch_bounds__(WG, HIER ? (KPL == 4 ? 3 : 4) : 1) void knn_kernel(
   const int L = threadIdx.x & (GL - 1);
   const int gshift = (threadIdx.x & 63) & ~(GL - 1);
   const Rec tr = tgt[list ? list[gid] : gid];  // `list`: positions (in the sorted target array) left over by the tile kernel
+#ifdef PT_VISITS
+  const unsigned long long pt_t0 = wall_clock64();
+#endif
   TargetGeom T;
   T.q[0] = (double)tr.x; T.q[1] = (double)tr.y; T.q[2] = (double)tr.z;
   T.h2 = gp.h * gp.h;
@@ -380,6 +406,22 @@ __global__ __launch_bounds__(WG, HIER ? (KPL == 4 ? 3 : 4) : 1) void knn_kernel(
           mS[j] = cs[km]; mE[j] = cs[km + 1];
         }
       }
+    }
+  }
+
+  if (ha.heavy) {                                           // group-uniform
+    uint32_t pop = (mE[0] - mS[0]) + (mE[1] - mS[1]) + (mE[2] - mS[2]);
+    uint32_t big = max(max(mE[0] - mS[0], mE[1] - mS[1]), mE[2] - mS[2]);
+    pop += (uint32_t)__shfl_xor((int)pop, 1, GL); pop += (uint32_t)__shfl_xor((int)pop, 2, GL); pop += (uint32_t)__shfl_xor((int)pop, 4, GL);
+    big = max(big, (uint32_t)__shfl_xor((int)big, 1, GL)); big = max(big, (uint32_t)__shfl_xor((int)big, 2, GL)); big = max(big, (uint32_t)__shfl_xor((int)big, 4, GL));
+    pop += (cE[0] - cS[0]) + (cE[1] - cS[1]) + (cE[2] - cS[2]);
+    big = max(big, max(max(cE[0] - cS[0], cE[1] - cS[1]), cE[2] - cS[2]));
+    if (pop >= ha.wave_min) {
+      // marked by position in the sorted target array (2: a refined cell among the 27 -- those need the descending variant of the
+      // wave kernel, which runs at half the occupancy); the marks are compacted IN ORDER afterwards, so that the wave kernel meets
+      // the targets cell by cell and neighbours share what they read through L2
+      if (L == 0) ha.heavy[list ? list[gid] : gid] = (HIER && big > ha.thr) ? 2u : 1u;
+      return;                                               // whole groups leave together
     }
   }
 
@@ -528,10 +570,10 @@ __global__ __launch_bounds__(WG, HIER ? (KPL == 4 ? 3 : 4) : 1) void knn_kernel(
           mask &= mask - 1;
           const uint32_t s0 = (uint32_t)__shfl(bs_, gshift + j), e0 = (uint32_t)__shfl(be_, gshift + j);
           for (uint32_t base = s0; base < e0; base += GL) {
-            const uint32_t p = base + (uint32_t)L;
+            const uint32_t p = base + (uint32_t)top.L;
             double d = INFINITY;
             uint32_t id = PT_NOIDX_U;
-            if (p < e0) { const Rec rc = src[p]; d = dist2(T.q, rc); id = rc.id; }
+            if (p < e0) { const Rec r = src[p]; d = dist2(T.q, r); id = r.id; }
             top.offer(d, id, gshift);
           }
         }
@@ -562,6 +604,366 @@ __global__ __launch_bounds__(WG, HIER ? (KPL == 4 ? 3 : 4) : 1) void knn_kernel(
       if (out_d2) out_d2[row + e] = top.ld[j];
     }
   }
+#ifdef PT_VISITS
+  __builtin_amdgcn_wave_barrier();
+  if (out_d2 && L == GL - 1) {                                              // (results are garbage in these columns)
+    out_d2[row + k - 1] = (double)top.nv * GL;
+    if (k >= 4) { out_d2[row + k - 2] = (double)(wall_clock64() - pt_t0); out_d2[row + k - 3] = (double)pt_t0; out_d2[row + k - 4] = (double)(blockIdx.x * 4u + threadIdx.x / 64u); }
+  }
+#endif
+}
+
+// =====================================================================================================================
+// Wave kernel: ONE WAVE (64 lanes) PER TARGET -- the targets of dense neighbourhoods (clouds with strong density contrast).
+//
+// Why a third kernel: the group kernel keeps eight targets per wave in lockstep, and in a dense cell every step of eight records
+// ends in the insertion path for SOME group (k ln(n / k) insertions per target, ~100 VALU instructions each at k = 32, seven
+// groups idle meanwhile): measured on the clustered generator it looks at 1e11 records/s whatever the index offers.  Here the
+// whole wave serves one target: 64 records per step with wave-uniform control flow; the sorted list lives one entry per lane
+// (rank i in lane i), so an insertion is one compare and one wave_shr:1 shift for the whole list (~12 instructions), and the
+// limit is a scalar.  Cells, shells, blocks and the rows of refined nodes are looked up 64 at a time, one per lane.
+// Same order, same bounds, same results as the group kernel (exact); k <= 64.
+constexpr int DPP_WAVE_SHR1 = 0x138;     // wave_shr:1: lane i <- lane i - 1 across the wave (lane 0 reads 0)
+constexpr int WV_RING_MAX = 31;          // a shell row (2 r + 1 cells) must fit the 64 lanes
+constexpr uint32_t WV_RUN = 16;          // consecutive workgroups (64 targets) that share an XCD
+
+__device__ inline double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ inline uint32_t readlane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+
+template <class Rec>
+struct WaveScan {
+  const Rec* __restrict__ src;
+  const uint32_t* __restrict__ nodes;
+  double q[3], u[3], h2;       // the target, its position in cell units, squared cell side: wave-uniform
+  double ld;                   // my entry of the sorted list: lane i holds rank i
+  uint32_t li;
+  double lim_d, bnd_d;         // acceptance limit = min(entry of rank k-1, caller's bound): wave-uniform
+  uint32_t lim_i;
+  int k, lane;
+#ifdef PT_VISITS
+  uint32_t nv = 0, nn = 0;     // instrumented build: steps of 64 records, nodes entered
+#endif
+
+  __device__ void reset() { ld = INFINITY; li = PT_NOIDX_U; lim_d = bnd_d; lim_i = PT_NOIDX_U; }
+  __device__ void refresh() {
+    const double kd = readlane_f64(ld, k - 1);
+    const uint32_t ki = readlane_u32(li, k - 1);
+    if (key_lt(kd, ki, bnd_d, PT_NOIDX_U)) { lim_d = kd; lim_i = ki; }
+    else { lim_d = bnd_d; lim_i = PT_NOIDX_U; }
+  }
+  // (xd, xi) wave-uniform: every entry that sorts after it moves up one lane, the first of them takes it
+  __device__ void insert(double xd, uint32_t xi) {
+    const bool gt = key_lt(xd, xi, ld, li);
+    const double pd = dpp_f64<DPP_WAVE_SHR1>(ld);
+    const uint32_t pi = dpp_u32<DPP_WAVE_SHR1>(li);
+    const bool pgt = dpp_u32<DPP_WAVE_SHR1>(gt ? 1u : 0u) != 0u;
+    if (gt) { ld = pgt ? pd : xd; li = pgt ? pi : xi; }
+  }
+  // one candidate per lane (d = +inf for lanes without one)
+  __device__ void offer(double d, uint32_t id) {
+    unsigned long long mask = __ballot(key_lt(d, id, lim_d, lim_i) && !(d > bnd_d));
+    while (mask) {                                          // wave-uniform
+      const int j = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const double xd = readlane_f64(d, j);
+      const uint32_t xi = readlane_u32(id, j);
+      if (!key_lt(xd, xi, lim_d, lim_i)) continue;          // the limit has moved since the ballot
+      insert(xd, xi);
+      refresh();
+    }
+  }
+  // WPF steps of loads are in flight while a step is ranked: with one, every step of 64 records cost a full memory latency (60 us
+  // per target at 25 - 35 steps, measured: the steps' arithmetic is ~0.15 us)
+  static constexpr int WPF = 1;
+  __device__ void range(uint32_t s, uint32_t e) {
+    Rec pq[WPF];
+#pragma unroll
+    for (int j = 0; j < WPF; ++j) {
+      const uint32_t p = s + (uint32_t)(j * 64 + lane);
+      if (p < e) pq[j] = src[p];
+    }
+    for (uint32_t base = s; base < e; base += 64u) {
+      const uint32_t p = base + (uint32_t)lane;
+      const Rec r = pq[0];
+#pragma unroll
+      for (int j = 0; j + 1 < WPF; ++j) pq[j] = pq[j + 1];
+      if (p + (uint32_t)(WPF * 64) < e) pq[WPF - 1] = src[p + (uint32_t)(WPF * 64)];
+      double d = INFINITY;
+      uint32_t id = PT_NOIDX_U;
+      if (p < e) { d = dist2(q, r); id = r.id; }
+#ifdef PT_VISITS
+      ++nv;
+#endif
+      offer(d, id);
+    }
+  }
+  // Up to 64 runs of records as ONE stream: lane j brings its run's first record S and length C (0: none); virtual record v of the
+  // stream is record v - P[j] of the run j whose prefix interval holds v.  64 records per step whatever the runs' lengths, and the
+  // next step's loads are in flight while this one is ranked -- a run costs no memory latency of its own (cell by cell, the 27
+  // cells of ring 1 cost 27: 40 us per target, measured).  No pruning inside the stream: the caller decides the runs beforehand.
+  __device__ void stream(uint32_t S, uint32_t C) {
+    const uint32_t pin = wave_incl_scan(C), pex = pin - C;
+    const uint32_t T = readlane_u32(pin, 63);
+    if (!T) return;                                         // wave-uniform
+    // my cursor: the run my current virtual record is in -- its interval [c_lo, c_hi) of the stream and its first record.  When a
+    // lane leaves its run, ALL lanes search the prefix sums again: a binary search of six shuffles, unrolled, with no loop around it
+    // (a `while any lane must advance` loop was turned by the compiler into one that lanes leave one by one, and a shuffle reads
+    // nothing from a lane that has left).
+    uint32_t c_lo = 0, c_hi = 0, c_S = 0;
+    auto locate = [&](uint32_t v) -> uint32_t {             // address of virtual record v (any value for v >= T)
+      const bool out = v < T && v >= c_hi;
+      if (__ballot(out) != 0ull) {                          // wave-uniform
+        int sg = 0;                                         // number of runs that end at or before v
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+          const uint32_t pe = (uint32_t)__shfl((int)pin, sg + step - 1);
+          sg += v >= pe ? step : 0;
+        }
+        sg = min(sg, 63);
+        const uint32_t nS = (uint32_t)__shfl((int)S, sg), nlo = (uint32_t)__shfl((int)pex, sg), nhi = (uint32_t)__shfl((int)pin, sg);
+        if (out) { c_S = nS; c_lo = nlo; c_hi = nhi; }
+      }
+      return c_S + (v - c_lo);
+    };
+    Rec pq[WPF];
+#pragma unroll
+    for (int j = 0; j < WPF; ++j) {
+      const uint32_t v = (uint32_t)(j * 64 + lane);
+      const uint32_t a = locate(v);
+      if (v < T) pq[j] = src[a];
+    }
+    for (uint32_t base = 0; base < T; base += 64u) {
+      const uint32_t v = base + (uint32_t)lane;
+      const Rec r = pq[0];
+#pragma unroll
+      for (int j = 0; j + 1 < WPF; ++j) pq[j] = pq[j + 1];
+      const uint32_t a = locate(v + (uint32_t)(WPF * 64));
+      if (v + (uint32_t)(WPF * 64) < T) pq[WPF - 1] = src[a];
+      double d = INFINITY;
+      uint32_t id = PT_NOIDX_U;
+      if (v < T) { d = dist2(q, r); id = r.id; }
+#ifdef PT_VISITS
+      ++nv;
+#endif
+      offer(d, id);
+    }
+  }
+  __device__ double gap2(int a, double lo, double hi) const {
+    const double g = fmax(fmax(lo - u[a], u[a] - hi) - PT_CELL_EPS, 0.0);
+    return g * g;
+  }
+  // refined cell (pt_refine.hip): the 64 rows of sub-cells are tested one per lane, the target's own sub-cell goes first.  Little is
+  // kept across a descent into a child (three levels of this are inlined into one another): the node's address, the rows still to
+  // visit, the children of the current row -- the header is read again (scalar loads) whenever a row needs its geometry.
+  template <int DEPTH>
+  __device__ void node(uint32_t nid) {
+    const uint32_t* N = nodes + (size_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)nid) - 1u) * PT_NODE_WORDS;     // (wave-uniform: scalar loads)
+    uint32_t own = 0xFFFFFFFFu;
+    unsigned long long live;
+#ifdef PT_VISITS
+    ++nn;
+#endif
+    {
+      const double* hd = reinterpret_cast<const double*>(N);
+      const double ox = hd[0], oy = hd[1], oz = hd[2], inv = hd[3], w = hd[4];
+      const double rx = (u[0] - ox) * inv, ry = (u[1] - oy) * inv, rz = (u[2] - oz) * inv;
+      if (rx >= 0.0 && rx < 8.0 && ry >= 0.0 && ry < 8.0 && rz >= 0.0 && rz < 8.0) own = (uint32_t)(((int)rz << 6) | ((int)ry << 3) | (int)rx);
+      const double fy = (double)(lane & 7), fz = (double)(lane >> 3);          // my row (sy, sz) = (lane & 7, lane >> 3)
+      const double s2 = gap2(1, oy + fy * w, oy + (fy + 1.0) * w) + gap2(2, oz + fz * w, oz + (fz + 1.0) * w);
+      live = __ballot(!(s2 * h2 > lim_d)) & ((unsigned long long)N[PT_NODE_ROWMASK] | ((unsigned long long)N[PT_NODE_ROWMASK + 1] << 32));
+    }
+    bool first = own != 0xFFFFFFFFu;
+    while (first || live) {                                 // wave-uniform
+      int r2, xa, xb;
+      if (first) { r2 = (int)(own >> 3); xa = xb = (int)(own & 7u); }
+      else {
+        r2 = __ffsll((long long)live) - 1;
+        live &= live - 1;
+        uint32_t again = 0;
+        asm volatile("" : "+s"(again));                     // (read the header again rather than keep it across the descents)
+        const double* hd = reinterpret_cast<const double*>(N + again);
+        const double ox = hd[0], oy = hd[1], oz = hd[2], w = hd[4];
+        const double fy = (double)(r2 & 7), fz = (double)(r2 >> 3);
+        const double t2 = gap2(1, oy + fy * w, oy + (fy + 1.0) * w) + gap2(2, oz + fz * w, oz + (fz + 1.0) * w);
+        if (t2 * h2 > lim_d) continue;                      // the limit has moved since the ballot
+        xa = 0; xb = 7;
+        while (xa <= xb && (gap2(0, ox + (double)xa * w, ox + (double)(xa + 1) * w) + t2) * h2 > lim_d) ++xa;
+        while (xb >= xa && (gap2(0, ox + (double)xb * w, ox + (double)(xb + 1) * w) + t2) * h2 > lim_d) --xb;
+        if (xa > xb) continue;
+      }
+      const bool sweep = !first;
+      first = false;
+      uint32_t stl = 0, chl = 0;                            // lane x: start of sub-cell x of the row (x = 8: its end) and its child
+      if (lane < 9) stl = N[PT_NODE_START + r2 * 8 + lane];
+      if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) { if (lane < 8) chl = N[PT_NODE_CHILD + r2 * 8 + lane]; }
+      // leaf sub-cells next to each other are one contiguous run of records, scanned in one go; a sub-cell that is a node, the own
+      // sub-cell (already done) and the end of the row cut the run.  The row's leaves first, then its children one by one.
+      uint32_t kids = 0, run_s = 0, run_e = 0;
+      for (int x = xa; x <= xb + 1; ++x) {
+        bool cut = x > xb || (sweep && (uint32_t)(r2 * 8 + x) == own);
+        if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) { if (!cut && readlane_u32(chl, x) != 0u) { kids |= 1u << x; cut = true; } }
+        if (!cut) {
+          if (run_e == run_s) run_s = readlane_u32(stl, x);
+          run_e = readlane_u32(stl, x + 1);
+          continue;
+        }
+        if (run_e > run_s) range(run_s, run_e);
+        run_s = run_e = 0;
+      }
+      if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) {
+        while (kids) {
+          const int x = __ffs((int)kids) - 1;
+          kids &= kids - 1;
+          node<DEPTH + 1>(readlane_u32(chl, x));
+        }
+      }
+    }
+  }
+};
+
+template <class Rec, bool HIER>
+__global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams gp, const Rec* __restrict__ src, const uint32_t* __restrict__ cs, const Rec* __restrict__ tgt,
+                                                      uint32_t m, int k, const double* __restrict__ bound2, uint32_t* __restrict__ out_idx,
+                                                      double* __restrict__ out_d2, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_n,
+                                                      HierArgs ha) {
+  // Consecutive workgroups go to different XCDs (8 of them, each with its own L2): hand the list out in runs of WV_RUN workgroups
+  // per XCD, so that the targets of neighbouring cells -- which read the same 27 cells -- meet in one L2, while all XCDs still
+  // advance through the list together (one contiguous eighth per XCD: the dense parts of the cloud end up on a few XCDs, 1.6 x slower).
+  const uint32_t count = list ? *list_n : m;
+  const uint32_t j = blockIdx.x >> 3, wgl = ((j / WV_RUN) * 8u + (blockIdx.x & 7u)) * WV_RUN + j % WV_RUN;
+  const uint32_t wid = wgl * 4u + (threadIdx.x >> 6);
+  if (wid >= count) return;                                 // whole waves leave together
+  const int lane = threadIdx.x & 63;
+  const Rec tr = tgt[list ? list[wid] : wid];
+#ifdef PT_VISITS
+  const unsigned long long pt_t0 = wall_clock64();
+#endif
+  WaveScan<Rec> W;
+  W.src = src; W.nodes = ha.nodes; W.k = k; W.lane = lane;
+  W.q[0] = (double)tr.x; W.q[1] = (double)tr.y; W.q[2] = (double)tr.z;
+  W.h2 = gp.h * gp.h;
+  int c[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    W.u[a] = (W.q[a] - gp.bbmin[a]) * gp.inv_h;
+    c[a] = (int)fmin(fmax(W.u[a], 0.0), (double)(gp.dim[a] - 1));
+  }
+  W.bnd_d = bound2 ? bound2[tr.id] : INFINITY;
+  W.reset();
+  auto cgap = [&](int a, int lo, int hi) -> double {        // as TargetGeom::gap
+    return fmax(fmax((double)lo - W.u[a], W.u[a] - (double)(hi + 1)) - PT_CELL_EPS, 0.0);
+  };
+  const int ring_limit = min(WV_RING_MAX, max(PT_RING_LIMIT, (int)cbrtf(0.07f * (float)gp.nblocks)));
+  // One loop serves ring 1 (27 cells, the target's own first, then its row, then the rest centre-first) and every further shell
+  // (step by step: a row or a column of the shell's cells per step), so that the scan and the descent exist once in the code.
+  int rr = 1, st = -1, nst = 0;
+  for (;;) {
+    int x = 0, y = 0, z = 0;
+    bool valid;
+    if (st < 0) {                                           // ring 1: lane i < 27 -> row i / 3 (centre-first), cell 0, -1, +1 of it
+      const int r = lane / 3, j = lane - 3 * r;
+      valid = lane < 27;
+      x = c[0] + (j == 0 ? 0 : (j == 1 ? -1 : 1)); y = c[1] + row_dy(valid ? r : 0); z = c[2] + row_dz(valid ? r : 0);
+    } else {
+      const int side = 2 * rr + 1;
+      int dx, dy, dz;
+      if (st < 2 * side) {                                  // the two full planes dz = -rr, +rr: a row of them per step, lanes along x
+        dz = st < side ? -rr : rr;
+        dy = -rr + (st < side ? st : st - side);
+        dx = -rr + lane;
+        valid = lane < side;
+      } else {                                              // planes in between: the perimeter, two rows (lanes along x) and two columns (lanes along y)
+        const int t = st - 2 * side, pz = t >> 2, kind = t & 3;
+        dz = -rr + 1 + pz;
+        if (kind < 2) { dy = kind ? rr : -rr; dx = -rr + lane; valid = lane < side; }
+        else { dx = kind == 3 ? rr : -rr; dy = -rr + 1 + lane; valid = lane < side - 2; }
+      }
+      x = c[0] + dx; y = c[1] + dy; z = c[2] + dz;
+    }
+    valid = valid && x >= 0 && x < gp.dim[0] && y >= 0 && y < gp.dim[1] && z >= 0 && z < gp.dim[2];
+    uint32_t key = 0, S = 0, E = 0;
+    double g2 = 0.0;
+    if (valid) {
+      key = cell_key(gp, x, y, z);
+      S = cs[key]; E = cs[key + 1];
+      const double gx = cgap(0, x, x), gy = cgap(1, y, y), gz = cgap(2, z, z);
+      g2 = gx * gx + gy * gy + gz * gz;
+    }
+    // refined cells are descended into (one by one: the target's own first); everything else of this step is ONE stream, after the
+    // own cell on the first step so that the bound it leaves decides which of the other 26 are read at all
+    uint32_t nid = 0;
+    if constexpr (HIER) { if (E - S > ha.thr) nid = ha.cell_node[key]; }       // (S == E == 0 for lanes without a cell)
+    if (st < 0) {
+      const uint32_t s0 = readlane_u32(S, 0), e0 = readlane_u32(E, 0), n0 = readlane_u32(nid, 0);
+      if (n0) W.template node<0>(n0);
+      else W.range(s0, e0);
+      if (lane == 0) { S = E = 0; nid = 0; }
+    }
+    const bool on = E > S && !(g2 * W.h2 > W.lim_d);
+    W.stream(S, on && !nid ? E - S : 0u);
+    if constexpr (HIER) {
+      unsigned long long want = __ballot(on && nid);
+      while (want) {                                        // wave-uniform
+        const int i = __ffsll((long long)want) - 1;
+        want &= want - 1;
+        if (readlane_f64(g2, i) * W.h2 > W.lim_d) continue; // the limit has moved since the ballot
+        W.template node<0>(readlane_u32(nid, i));
+      }
+    }
+    if (st >= 0 && ++st < nst) continue;
+    // ring rr is complete: every unscanned point lies beyond one of the box faces that still has cells behind it
+    bool covered = true;
+    double dout = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int lo = c[a] - rr, hi = c[a] + rr;
+      if (lo > 0) { covered = false; dout = fmin(dout, W.u[a] - (double)lo); }
+      if (hi < gp.dim[a] - 1) { covered = false; dout = fmin(dout, (double)(hi + 1) - W.u[a]); }
+    }
+    if (covered) break;
+    dout = fmax(dout - PT_CELL_EPS, 0.0);
+    if (dout * dout * W.h2 > W.lim_d) break;
+    if (rr >= ring_limit) {
+      // far from the points: sweep the BLOCKS (skip the empty ones, prune by box, scan the rest), the list started again so that
+      // no point is offered twice -- as the group kernel does, 64 blocks per step
+      W.reset();
+      const uint32_t nb = (uint32_t)gp.nblocks;
+      for (uint32_t b0 = 0; b0 < nb; b0 += 64u) {
+        const uint32_t b = b0 + (uint32_t)lane;
+        uint32_t bs_ = 0, be_ = 0;
+        double bg2 = 0.0;
+        if (b < nb) { bs_ = cs[(size_t)b * PT_BLOCK_CELLS]; be_ = cs[((size_t)b + 1) * PT_BLOCK_CELLS]; }
+        if (be_ > bs_) {
+          const uint32_t macro = b >> 9, m9 = b & 511u;
+          const int bx = (int)(macro % (uint32_t)gp.mdim[0]) * 8 + (int)((m9 & 1u) | ((m9 >> 2) & 2u) | ((m9 >> 4) & 4u));
+          const int by = (int)((macro / (uint32_t)gp.mdim[0]) % (uint32_t)gp.mdim[1]) * 8 + (int)(((m9 >> 1) & 1u) | ((m9 >> 3) & 2u) | ((m9 >> 5) & 4u));
+          const int bz = (int)(macro / (uint32_t)(gp.mdim[0] * gp.mdim[1])) * 8 + (int)(((m9 >> 2) & 1u) | ((m9 >> 4) & 2u) | ((m9 >> 6) & 4u));
+          const double gx = cgap(0, bx * 8, bx * 8 + 7), gy = cgap(1, by * 8, by * 8 + 7), gz = cgap(2, bz * 8, bz * 8 + 7);
+          bg2 = gx * gx + gy * gy + gz * gz;
+        }
+        W.stream(bs_, be_ > bs_ && !(bg2 * W.h2 > W.lim_d) ? be_ - bs_ : 0u);
+      }
+      break;
+    }
+    ++rr;
+    st = 0;
+    nst = 2 * (2 * rr + 1) + 4 * (2 * rr - 1);
+  }
+  if (lane < k) {
+    const size_t row = (size_t)tr.id * (size_t)k;
+    out_idx[row + lane] = W.li;
+    if (out_d2) out_d2[row + lane] = W.ld;
+  }
+#ifdef PT_VISITS
+  __builtin_amdgcn_wave_barrier();
+  if (out_d2 && lane == 0 && k >= 4) {                      // (results are garbage in these columns)
+    const size_t row = (size_t)tr.id * (size_t)k;
+    out_d2[row + k - 1] = (double)W.nv * 64.0; out_d2[row + k - 2] = (double)(wall_clock64() - pt_t0); out_d2[row + k - 3] = (double)pt_t0;
+    out_d2[row + k - 4] = -(double)(W.nn + 1u);            // negative: a wave-kernel row, and how many nodes it entered (+1)
+  }
+#endif
 }
 
 // =====================================================================================================================
@@ -1212,10 +1614,10 @@ template void pt_launch_request_pack<double>(const double*, const double*, const
 
 template <class Rec>
 void pt_launch_knn(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const Rec* tgt, uint32_t m, int k, const double* bound2,
-                   uint32_t* out_idx, double* out_d2, const uint32_t* list, const uint32_t* list_n, hipStream_t s) {
+                   uint32_t* out_idx, double* out_d2, const uint32_t* list, const uint32_t* list_n, hipStream_t s, uint8_t* heavy, uint32_t wave_min) {
   if (!m) return;
   const uint32_t nwg = (uint32_t)(((uint64_t)m * GL + WG - 1) / WG);
-  const HierArgs ha{nullptr, nullptr, 0xFFFFFFFFu};
+  const HierArgs ha{nullptr, nullptr, 0xFFFFFFFFu, heavy, wave_min};
   if (k <= 8)
     hipLaunchKernelGGL((knn_kernel<Rec, 1, false>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n, ha);
   else if (k <= 16)
@@ -1224,17 +1626,17 @@ void pt_launch_knn(const GridParams& gp, const Rec* src, const uint32_t* cell_st
     hipLaunchKernelGGL((knn_kernel<Rec, 4, false>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n, ha);
 }
 template void pt_launch_knn<RecF>(const GridParams&, const RecF*, const uint32_t*, const RecF*, uint32_t, int, const double*, uint32_t*, double*,
-                                  const uint32_t*, const uint32_t*, hipStream_t);
+                                  const uint32_t*, const uint32_t*, hipStream_t, uint8_t*, uint32_t);
 template void pt_launch_knn<RecD>(const GridParams&, const RecD*, const uint32_t*, const RecD*, uint32_t, int, const double*, uint32_t*, double*,
-                                  const uint32_t*, const uint32_t*, hipStream_t);
+                                  const uint32_t*, const uint32_t*, hipStream_t, uint8_t*, uint32_t);
 
 template <class Rec>
 void pt_launch_knn_hier(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const uint32_t* cell_node, const uint32_t* nodes, uint32_t node_thr,
                         const Rec* tgt, uint32_t m, int k, const double* bound2, uint32_t* out_idx, double* out_d2, const uint32_t* list,
-                        const uint32_t* list_n, hipStream_t s) {
+                        const uint32_t* list_n, hipStream_t s, uint8_t* heavy, uint32_t wave_min) {
   if (!m) return;
   const uint32_t nwg = (uint32_t)(((uint64_t)m * GL + WG - 1) / WG);
-  const HierArgs ha{cell_node, nodes, node_thr};
+  const HierArgs ha{cell_node, nodes, node_thr, heavy, wave_min};
   if (k <= 8)
     hipLaunchKernelGGL((knn_kernel<Rec, 1, true>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n, ha);
   else if (k <= 16)
@@ -1243,8 +1645,76 @@ void pt_launch_knn_hier(const GridParams& gp, const Rec* src, const uint32_t* ce
     hipLaunchKernelGGL((knn_kernel<Rec, 4, true>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, m, k, bound2, out_idx, out_d2, list, list_n, ha);
 }
 template void pt_launch_knn_hier<RecF>(const GridParams&, const RecF*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const RecF*, uint32_t, int, const double*,
-                                       uint32_t*, double*, const uint32_t*, const uint32_t*, hipStream_t);
+                                       uint32_t*, double*, const uint32_t*, const uint32_t*, hipStream_t, uint8_t*, uint32_t);
 template void pt_launch_knn_hier<RecD>(const GridParams&, const RecD*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const RecD*, uint32_t, int, const double*,
+                                       uint32_t*, double*, const uint32_t*, const uint32_t*, hipStream_t, uint8_t*, uint32_t);
+
+// ---- the marks of the group kernel, compacted in order: positions with mark 1 to list1, with mark 2 to list2 ----------------------
+constexpr int CP_ITEMS = 8, CP_TILE = WG * CP_ITEMS;
+__global__ __launch_bounds__(WG) void mark_count_kernel(const uint8_t* __restrict__ mark, uint32_t m, uint32_t* __restrict__ c1, uint32_t* __restrict__ c2) {
+  __shared__ uint32_t wsum[4];
+  uint32_t a = 0, b = 0;
+#pragma unroll
+  for (int i = 0; i < CP_ITEMS; ++i) {
+    const uint32_t t = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS + i;
+    const uint32_t v = t < m ? mark[t] : 0u;
+    a += v == 1u; b += v == 2u;
+  }
+  uint32_t ta, tb;
+  block_excl_scan(a, wsum, ta);
+  __syncthreads();
+  block_excl_scan(b, wsum, tb);
+  if (threadIdx.x == 0) { c1[blockIdx.x] = ta; c2[blockIdx.x] = tb; }
+}
+__global__ __launch_bounds__(WG) void mark_write_kernel(const uint8_t* __restrict__ mark, uint32_t m, const uint32_t* __restrict__ o1, const uint32_t* __restrict__ o2,
+                                                        uint32_t* __restrict__ list1, uint32_t* __restrict__ list2) {
+  __shared__ uint32_t wsum[4];
+  uint32_t v[CP_ITEMS], a = 0, b = 0;
+#pragma unroll
+  for (int i = 0; i < CP_ITEMS; ++i) {
+    const uint32_t t = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS + i;
+    v[i] = t < m ? mark[t] : 0u;
+    a += v[i] == 1u; b += v[i] == 2u;
+  }
+  uint32_t ta, tb;
+  uint32_t ea = o1[blockIdx.x] + block_excl_scan(a, wsum, ta);
+  __syncthreads();
+  uint32_t eb = o2[blockIdx.x] + block_excl_scan(b, wsum, tb);
+#pragma unroll
+  for (int i = 0; i < CP_ITEMS; ++i) {
+    const uint32_t t = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS + i;
+    if (v[i] == 1u) list1[ea++] = t;
+    else if (v[i] == 2u) list2[eb++] = t;
+  }
+}
+// counts -> cnt[nt + 1] each (exclusive offsets, the totals in the last entry); scratch: 2 * (nt + 1) + scan scratch words
+void pt_launch_mark_count(const uint8_t* mark, uint32_t m, uint32_t* off1, uint32_t* off2, uint32_t* scan_tmp, hipStream_t s) {
+  const uint32_t nt = (m + CP_TILE - 1) / CP_TILE;
+  (void)hipMemsetAsync(off1 + nt, 0, 4, s); (void)hipMemsetAsync(off2 + nt, 0, 4, s);
+  if (nt) hipLaunchKernelGGL(mark_count_kernel, dim3(nt), dim3(WG), 0, s, mark, m, off1, off2);
+  pt_launch_scan_u32(off1, off1, nt + 1, scan_tmp, s);
+  pt_launch_scan_u32(off2, off2, nt + 1, scan_tmp, s);
+}
+void pt_launch_mark_write(const uint8_t* mark, uint32_t m, const uint32_t* off1, const uint32_t* off2, uint32_t* list1, uint32_t* list2, hipStream_t s) {
+  const uint32_t nt = (m + CP_TILE - 1) / CP_TILE;
+  if (nt) hipLaunchKernelGGL(mark_write_kernel, dim3(nt), dim3(WG), 0, s, mark, m, off1, off2, list1, list2);
+}
+uint32_t pt_mark_tiles(uint32_t m) { return (m + CP_TILE - 1) / CP_TILE; }
+
+// wave kernel over a list of `count` target positions (list == nullptr: all m targets); cell_node / nodes may be null (no refined cells)
+template <class Rec>
+void pt_launch_knn_wave(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const uint32_t* cell_node, const uint32_t* nodes, uint32_t node_thr,
+                        const Rec* tgt, uint32_t count, int k, const double* bound2, uint32_t* out_idx, double* out_d2, const uint32_t* list,
+                        const uint32_t* list_n, hipStream_t s) {
+  if (!count) return;
+  const uint32_t nwg = (((count + 3u) / 4u + 8u * WV_RUN - 1u) / (8u * WV_RUN)) * 8u * WV_RUN;      // whole rounds of 8 XCDs x WV_RUN workgroups (the kernel's mapping)
+  const HierArgs ha{cell_node, nodes, node_thr, nullptr, 0u};
+  if (nodes) hipLaunchKernelGGL((knn_wave_kernel<Rec, true>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, count, k, bound2, out_idx, out_d2, list, list_n, ha);
+  else hipLaunchKernelGGL((knn_wave_kernel<Rec, false>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, count, k, bound2, out_idx, out_d2, list, list_n, ha);
+}
+template void pt_launch_knn_wave<RecF>(const GridParams&, const RecF*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const RecF*, uint32_t, int, const double*,
+                                       uint32_t*, double*, const uint32_t*, const uint32_t*, hipStream_t);
+template void pt_launch_knn_wave<RecD>(const GridParams&, const RecD*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const RecD*, uint32_t, int, const double*,
                                        uint32_t*, double*, const uint32_t*, const uint32_t*, hipStream_t);
 
 // tile kernel over all blocks; targets it cannot settle are appended to todo[*todo_n] (todo_n zeroed by the caller).

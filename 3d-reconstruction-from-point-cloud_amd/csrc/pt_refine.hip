@@ -110,6 +110,15 @@ __global__ __launch_bounds__(RW) void refine_nodes_kernel(GridParams gp, Rec* __
   __syncthreads();
   cnt[threadIdx.x] = ex;                                    // cursor, relative to s
   N[PT_NODE_START + threadIdx.x] = s + ex;                  // (entry 512 = e is already there)
+  {                                                         // which rows of eight sub-cells hold anything: what a search looks at first
+    const unsigned long long nz = __ballot(c0 != 0u);       // wave w covers sub-cells 64 w .. 64 w + 63 = rows 8 w .. 8 w + 7
+    if (lane == 0) {
+      uint32_t rows8 = 0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) rows8 |= ((nz >> (8 * r)) & 0xFFull) ? (1u << r) : 0u;
+      reinterpret_cast<unsigned char*>(N + PT_NODE_ROWMASK)[w] = (unsigned char)rows8;
+    }
+  }
   __syncthreads();
   if (in_regs) {                                            // everything is in registers: the range can be rewritten in place
 #pragma unroll

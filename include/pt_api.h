@@ -91,7 +91,7 @@ typedef struct pt_stats_t {
   uint32_t n_nodes;         /* last build: refined ("heavy") cells and sub-cells that carry an 8x8x8 sub-grid (0: none needed) */
   int32_t refine_levels;    /* ... and how many levels deep (<= 3) */
   uint32_t max_cell_points; /* points of the fullest grid cell of the last build (adaptive builds) */
-  uint32_t _pad2;
+  uint32_t n_wave;          /* last query: targets answered by the one-wave-per-target kernel (dense neighbourhoods) */
 } pt_stats_t;
 
 /* ---- context ------------------------------------------------------------------------ */
@@ -110,7 +110,11 @@ int  pt_set_stream(pt_ctx*, void* hip_stream);
  * large tile geometry), "guess_min_points" (clouds at least this large lay their grid out from the bounding box of a
  * sample and verify it during the first partition pass instead of spending a pass on the exact box; default 8 Mi),
  * "refine_threshold" (grid cells holding more points than this get an 8x8x8 sub-grid, recursively up to three levels, which
- * searches descend into instead of scanning the cell end to end -- clouds with strong density contrast; default 2048, 0 = never). */
+ * searches descend into instead of scanning the cell end to end -- clouds with strong density contrast; default 2048, 0 = never),
+ * "wave_min" (on such clouds a target whose 27 nearest cells hold at least this many points is answered by a whole wave instead of
+ * an 8-lane group; default 512, 0 = never; "wave_force" = 1 applies that split to every cloud -- a testing hook), "refine_macros"
+ * (the finest grid the refinement of the cell size may ask for, in 64^3-cell macro blocks: default 1024, at most 8192 -- grids beyond
+ * 1024 macro blocks, which a cloud of more than ~1e9 points gets anyway, cost the sort one more partition pass). */
 int  pt_set_param(pt_ctx*, const char* name, double value);
 const char* pt_last_error(pt_ctx*);
 int  pt_stats(pt_ctx*, pt_stats_t* out);

@@ -1114,6 +1114,66 @@ def test_refined_cells_are_exact(pkg, oracle, kind, k, f64, thr):
         _check_exact(p.query(tgt, k), want, "unrefined %s" % kind)
 
 
+@pytest.mark.parametrize("kind,k,f64,thr,rho", [("blobs", 8, False, 0, None), ("blobs", 32, True, 48, None), ("sheet", 20, False, 3, None), ("lattice", 8, False, 0, None),
+                                                ("lattice", 32, False, 32, None), ("line", 16, True, 3, None), ("uniform", 32, False, 0, 0.4), ("uniform", 8, True, 0, None)])
+def test_wave_kernel_is_exact(pkg, oracle, kind, k, f64, thr, rho):
+    """One wave per target (knn_wave_kernel), forced for every target with a single point in its 27 nearest cells: dense cells,
+    refined cells (thr > 0: descended into, 64 rows per step), sparse neighbourhoods that need several shells (rho 0.4 at k = 32), a
+    target next to a lone outlier (block sweep), radius-bounded queries -- all equal to brute force bit for bit."""
+    import torch
+    from test_gpu_stress import _cloud
+    rng = np.random.default_rng(900 + k)
+    n, m = 50000, 2500
+    src = _cloud(rng, kind, n); tgt = _cloud(rng, kind, m)
+    if kind in ("blobs", "lattice"):
+        src[:, -1] = np.float32(40.0)                                          # a lone point far away ...
+        tgt[:, 0] = np.float32(40.0) + np.float32(1e-3)                        # ... and a target beside it: everything else is 40 units off
+    tgt[:, 1:60] = tgt[:, 1:60] * np.float32(2.0) - np.float32(0.5)            # some targets around the cloud's edge
+    tgt[:, 100:300] = src[:, rng.integers(0, n, 200)]
+    if f64:
+        src = src.astype(np.float64) + (rng.random(src.shape) - 0.5) * 1e-9 * (kind != "lattice"); tgt = tgt.astype(np.float64)
+    want = oracle.knn_bruteforce(src, tgt, k)
+    with pkg.PointsTransfer(device=0, k_hint=min(k, 32), rho=rho) as p:
+        p.set_param("refine_threshold", thr); p.set_param("tile", 0); p.set_param("wave_force", 1); p.set_param("wave_min", 1)
+        p.build(src)
+        st = p.stats()
+        assert (st["n_nodes"] > 0) == (thr > 0), st
+        got = p.query(tgt, k)
+        assert p.stats()["n_wave"] >= m // 4, p.stats()                          # (targets with 27 empty cells around them stay with the group kernel)
+        _check_exact(got, want, "wave %s" % kind)
+        bnd = want[1][:, k - 1].copy(); bnd[::2] *= 0.5
+        xt = pkg.F64 if f64 else pkg.F32
+        x = torch.from_numpy(np.ascontiguousarray(tgt)).cuda(); b = torch.from_numpy(bnd).cuda()
+        bi = torch.empty((m, k), dtype=torch.int32, device="cuda"); bd = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        p.query_bounded_dev(x, xt, b, m, k, bi, bd)
+        torch.cuda.synchronize()
+        bi = bi.cpu().numpy().view(np.uint32); bd = bd.cpu().numpy()
+        keep = want[1] <= bnd[:, None]
+        assert np.array_equal(np.where(keep, want[0], 0xFFFFFFFF), bi) and np.array_equal(np.where(keep, want[1], np.inf), bd)
+
+
+@pytest.mark.parametrize("kind,f64", [("uniform", False), ("blobs", False), ("sheet", True)])
+def test_three_level_sort_for_very_fine_grids(pkg, oracle, kind, f64):
+    """More than 1024 macro blocks (64^3 cells each): the sort partitions by GROUPS of macro blocks first, then by macro block, then
+    by block -- one pass more than usual.  Forced here with a tiny rho (a grid of ~1e9 cells over 300 k points); searches through the
+    tile kernel and through the group kernel equal brute force bit for bit."""
+    from test_gpu_stress import _cloud
+    rng = np.random.default_rng(31)
+    n, m, k = 300000, 2000, 8
+    src = _cloud(rng, kind, n); tgt = _cloud(rng, kind, m)
+    tgt[:, :50] = tgt[:, :50] * np.float32(1.5) - np.float32(0.25)
+    if f64:
+        src = src.astype(np.float64) + (rng.random(src.shape) - 0.5) * 1e-9; tgt = tgt.astype(np.float64)
+    want = oracle.knn_bruteforce(src, tgt, k)
+    for tile in (0, 1):
+        with pkg.PointsTransfer(device=0, rho=0.0004) as p:
+            p.set_param("adaptive", 0); p.set_param("tile", tile)
+            p.build(src)
+            st = p.stats()
+            assert st["n_levels"] == 3, st
+            _check_exact(p.query(tgt, k), want, "three-level %s tile=%d" % (kind, tile))
+
+
 def test_full_size_clustered_sampled_against_oracle(pkg, oracle):
     """BASELINE config 5's distribution at 100 M points (thin patches + blobs + a little uniform; cells of the fullest clump hold tens
     of thousands of points and get sub-grids): the search of 5 M jittered targets is exact on a sample against the CPU kd-tree."""
