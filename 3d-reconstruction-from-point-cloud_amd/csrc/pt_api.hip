@@ -71,9 +71,10 @@ struct pt_ctx {
                                         // generator: beyond 1024 the extra sort pass costs more than the shorter scans save)
   int wave_force = 0;                   // 1: the heavy / light split also on clouds without density contrast (tests, tuning)
   uint32_t wave_min = 512;              // targets with at least this many points in their 27 nearest cells get a wave each (0: never)
-  double refine_threshold = 2048.0;     // 0: never refine.  Measured on the clustered generator (tools/probe_clustered.py): descending into a
-                                        // sub-grid beats scanning the cell end to end from a few thousand points up -- 1B / 50M / k = 32: 3.16 s
-                                        // unrefined, 2.23 s at 512, 2.12 s at 2048; 100M / 5M / k = 8: 34.1 / 42.1 / 35.8 / 37.7 ms at 0 / 512 / 2048 / 8192
+  double refine_threshold = 8192.0;     // 0: never refine.  Measured on the clustered generator (tools/probe_wave.py) with the wave kernel taking the dense
+                                        // neighbourhoods: a descent costs several dependent memory round trips, a scan of 64 records per step does
+                                        // not, so only cells of many thousands of points are worth a sub-grid -- 1B / 50M / k = 32: 675 ms unrefined,
+                                        // 585 / 565 / 553 / 554 at 2048 / 4096 / 8192 / 16384; 100M / 5M / k = 8: 20.3 / 22.1 / 21.9 / 21.2 / 21.1 ms
   DevBuf cell_node, nodes;
   uint32_t n_nodes = 0, refine_levels = 0;
   // slab exchange (pt_comm_* / pt_exchange_*)

@@ -627,6 +627,12 @@ constexpr int DPP_WAVE_SHR1 = 0x138;     // wave_shr:1: lane i <- lane i - 1 acr
 constexpr int WV_RING_MAX = 31;          // a shell row (2 r + 1 cells) must fit the 64 lanes
 constexpr uint32_t WV_RUN = 16;          // consecutive workgroups (64 targets) that share an XCD
 
+// key_lt without short-circuit evaluation: no branches around the comparisons (the compiler turns `a < b || (a == b && i < j)` on
+// per-lane values into three exec-masked blocks)
+__device__ inline bool key_lt_flat(double ad, uint32_t ai, double bd, uint32_t bi) {
+  const bool lt = ad < bd, eq = ad == bd, il = ai < bi;
+  return lt | (eq & il);
+}
 __device__ inline double readlane_f64(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
@@ -650,26 +656,55 @@ struct WaveScan {
   __device__ void refresh() {
     const double kd = readlane_f64(ld, k - 1);
     const uint32_t ki = readlane_u32(li, k - 1);
-    if (key_lt(kd, ki, bnd_d, PT_NOIDX_U)) { lim_d = kd; lim_i = ki; }
+    if (key_lt_flat(kd, ki, bnd_d, PT_NOIDX_U)) { lim_d = kd; lim_i = ki; }
     else { lim_d = bnd_d; lim_i = PT_NOIDX_U; }
   }
   // (xd, xi) wave-uniform: every entry that sorts after it moves up one lane, the first of them takes it
   __device__ void insert(double xd, uint32_t xi) {
-    const bool gt = key_lt(xd, xi, ld, li);
+    const bool gt = key_lt_flat(xd, xi, ld, li);
     const double pd = dpp_f64<DPP_WAVE_SHR1>(ld);
     const uint32_t pi = dpp_u32<DPP_WAVE_SHR1>(li);
     const bool pgt = dpp_u32<DPP_WAVE_SHR1>(gt ? 1u : 0u) != 0u;
     if (gt) { ld = pgt ? pd : xd; li = pgt ? pi : xi; }
   }
+  // Many candidates at once (the first steps of a target: with fewer than k points seen every record is one): sort the 64 candidate
+  // slots across the lanes (bitonic, 21 exchange stages), take the 64 smallest of list and candidates (list[i] against candidate
+  // [63 - i]) and sort that bitonic sequence (6 stages) -- ~400 instructions whatever the number of candidates, against ~60 for
+  // each one-by-one insertion.  Keys are distinct (ids) except the empty slots (+inf, NOIDX), whose order does not matter.
+  __device__ static void exchange(double& xd, uint32_t& xi, int j, bool keep_min) {
+    const double pd = __shfl_xor(xd, j);
+    const uint32_t pi = (uint32_t)__shfl_xor((int)xi, j);
+    const bool take = keep_min ? key_lt_flat(pd, pi, xd, xi) : key_lt_flat(xd, xi, pd, pi);
+    if (take) { xd = pd; xi = pi; }
+  }
+  __device__ void merge64(double cd, uint32_t ci) {
+#pragma unroll 1
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {                  // (rolled: one exchange body instead of 27, and no table of lane masks in SGPRs)
+#pragma unroll 1
+      for (int j = k2 >> 1; j > 0; j >>= 1) exchange(cd, ci, j, ((lane & j) == 0) == ((lane & k2) == 0));
+    }
+    const double rd = __shfl(cd, 63 - lane);
+    const uint32_t ri = (uint32_t)__shfl((int)ci, 63 - lane);
+    if (key_lt_flat(rd, ri, ld, li)) { ld = rd; li = ri; }
+#pragma unroll 1
+    for (int j = 32; j > 0; j >>= 1) exchange(ld, li, j, (lane & j) == 0);
+  }
+  static constexpr int MERGE_MIN = 16;
   // one candidate per lane (d = +inf for lanes without one)
   __device__ void offer(double d, uint32_t id) {
-    unsigned long long mask = __ballot(key_lt(d, id, lim_d, lim_i) && !(d > bnd_d));
+    const bool pass = key_lt_flat(d, id, lim_d, lim_i) && !(d > bnd_d);
+    unsigned long long mask = __ballot(pass);
+    if (__popcll(mask) >= MERGE_MIN) {                      // wave-uniform
+      merge64(pass ? d : INFINITY, pass ? id : PT_NOIDX_U);
+      refresh();
+      return;
+    }
     while (mask) {                                          // wave-uniform
       const int j = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
       const double xd = readlane_f64(d, j);
       const uint32_t xi = readlane_u32(id, j);
-      if (!key_lt(xd, xi, lim_d, lim_i)) continue;          // the limit has moved since the ballot
+      if (!key_lt_flat(xd, xi, lim_d, lim_i)) continue;          // the limit has moved since the ballot
       insert(xd, xi);
       refresh();
     }

@@ -110,7 +110,7 @@ int  pt_set_stream(pt_ctx*, void* hip_stream);
  * large tile geometry), "guess_min_points" (clouds at least this large lay their grid out from the bounding box of a
  * sample and verify it during the first partition pass instead of spending a pass on the exact box; default 8 Mi),
  * "refine_threshold" (grid cells holding more points than this get an 8x8x8 sub-grid, recursively up to three levels, which
- * searches descend into instead of scanning the cell end to end -- clouds with strong density contrast; default 2048, 0 = never),
+ * searches descend into instead of scanning the cell end to end -- clouds with strong density contrast; default 8192, 0 = never),
  * "wave_min" (on such clouds a target whose 27 nearest cells hold at least this many points is answered by a whole wave instead of
  * an 8-lane group; default 512, 0 = never; "wave_force" = 1 applies that split to every cloud -- a testing hook), "refine_macros"
  * (the finest grid the refinement of the cell size may ask for, in 64^3-cell macro blocks: default 1024, at most 8192 -- grids beyond
