@@ -637,6 +637,15 @@ __device__ inline double readlane_f64(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 __device__ inline uint32_t readlane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+// lane l of v := the wave-uniform value x (no builtin for it in this compiler).  M0 is free in the kernels that use this (no LDS-DMA,
+// no GWS): the compiler's warning about the clobber is silenced.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ inline uint32_t writelane_u32(uint32_t v, uint32_t x, int l) {
+  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(x), "s"(l) : "m0");     // (one SGPR per VOP3: the lane goes through M0)
+  return v;
+}
+#pragma clang diagnostic pop
 
 template <class Rec>
 struct WaveScan {
@@ -659,13 +668,20 @@ struct WaveScan {
     if (key_lt_flat(kd, ki, bnd_d, PT_NOIDX_U)) { lim_d = kd; lim_i = ki; }
     else { lim_d = bnd_d; lim_i = PT_NOIDX_U; }
   }
-  // (xd, xi) wave-uniform: every entry that sorts after it moves up one lane, the first of them takes it
-  __device__ void insert(double xd, uint32_t xi) {
+  // (xd, xi) wave-uniform.  The entries that sort after it are a run of lanes [p, 63] (the list is sorted): they shift up one lane
+  // -- DPP moves executed by THOSE lanes only (lane p reads lane p - 1, which is switched off: bound_ctrl hands it a 0 that the
+  // next line overwrites) -- and lane p takes the new entry by v_writelane.  ~25 instructions; the compare-everything-and-select
+  // form of the same was ~58, and insertions are two thirds of this kernel's instructions on dense data.
+  // Returns the lane the entry went to (64: nowhere).
+  __device__ int insert(double xd, uint32_t xi) {
     const bool gt = key_lt_flat(xd, xi, ld, li);
-    const double pd = dpp_f64<DPP_WAVE_SHR1>(ld);
-    const uint32_t pi = dpp_u32<DPP_WAVE_SHR1>(li);
-    const bool pgt = dpp_u32<DPP_WAVE_SHR1>(gt ? 1u : 0u) != 0u;
-    if (gt) { ld = pgt ? pd : xd; li = pgt ? pi : xi; }
+    const unsigned long long after = __ballot(gt);
+    if (!after) return 64;                                   // wave-uniform
+    const int p = __ffsll((long long)after) - 1;
+    if (gt) { ld = dpp_f64<DPP_WAVE_SHR1>(ld); li = dpp_u32<DPP_WAVE_SHR1>(li); }
+    ld = __hiloint2double((int)writelane_u32((uint32_t)__double2hiint(ld), (uint32_t)__double2hiint(xd), p), (int)writelane_u32((uint32_t)__double2loint(ld), (uint32_t)__double2loint(xd), p));
+    li = writelane_u32(li, xi, p);
+    return p;
   }
   // Many candidates at once (the first steps of a target: with fewer than k points seen every record is one): sort the 64 candidate
   // slots across the lanes (bitonic, 21 exchange stages), take the 64 smallest of list and candidates (list[i] against candidate
@@ -704,9 +720,8 @@ struct WaveScan {
       mask &= mask - 1;
       const double xd = readlane_f64(d, j);
       const uint32_t xi = readlane_u32(id, j);
-      if (!key_lt_flat(xd, xi, lim_d, lim_i)) continue;          // the limit has moved since the ballot
-      insert(xd, xi);
-      refresh();
+      // (no second look at the limit: a candidate that no longer beats it lands beyond rank k - 1, where it is harmless)
+      if (insert(xd, xi) < k) refresh();
     }
   }
   // WPF steps of loads are in flight while a step is ranked: with one, every step of 64 records cost a full memory latency (60 us
