@@ -687,10 +687,14 @@ struct WaveScan {
   // slots across the lanes (bitonic, 21 exchange stages), take the 64 smallest of list and candidates (list[i] against candidate
   // [63 - i]) and sort that bitonic sequence (6 stages) -- ~400 instructions whatever the number of candidates, against ~60 for
   // each one-by-one insertion.  Keys are distinct (ids) except the empty slots (+inf, NOIDX), whose order does not matter.
-  __device__ static void exchange(double& xd, uint32_t& xi, int j, bool keep_min) {
-    const double pd = __shfl_xor(xd, j);
-    const uint32_t pi = (uint32_t)__shfl_xor((int)xi, j);
-    const bool take = keep_min ? key_lt_flat(pd, pi, xd, xi) : key_lt_flat(xd, xi, pd, pi);
+  // (raw ds_bpermute on a byte address: HIP's __shfl_xor spends four more instructions per call on range checks)
+  __device__ void exchange(double& xd, uint32_t& xi, int j, bool keep_min) const {
+    const int a = (lane ^ j) << 2;
+    const int plo = __builtin_amdgcn_ds_bpermute(a, __double2loint(xd)), phi = __builtin_amdgcn_ds_bpermute(a, __double2hiint(xd));
+    const uint32_t pi = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)xi);
+    const double pd = __hiloint2double(phi, plo);
+    // partner < mine, or mine < partner: the keys differ unless both slots are empty (then nothing moves)
+    const bool plt = key_lt_flat(pd, pi, xd, xi), take = keep_min ? plt : (!plt && !(pd == xd && pi == xi));
     if (take) { xd = pd; xi = pi; }
   }
   __device__ void merge64(double cd, uint32_t ci) {
