@@ -69,6 +69,7 @@ struct pt_ctx {
   // refinement of heavy cells (pt_refine.hip): sub-grids inside cells with more than refine_threshold points
   int refine_macros = PT_MAXBINS;       // finest grid the occupancy-driven refinement of h may ask for, in macro blocks (measured on the clustered
                                         // generator: beyond 1024 the extra sort pass costs more than the shorter scans save)
+  bool grid_capped = false;             // the last choose_grid ran into the macro-block limit: no finer grid exists
   int wave_force = 0;                   // 1: the heavy / light split also on clouds without density contrast (tests, tuning)
   uint32_t wave_min = 512;              // targets with at least this many points in their 27 nearest cells get a wave each (0: never)
   double refine_threshold = 8192.0;     // 0: never refine.  Measured on the clustered generator (tools/probe_wave.py) with the wave kernel taking the dense
@@ -197,8 +198,9 @@ void choose_grid(pt_ctx* c, const double mn[3], const double mx[3], double force
     h = std::max(h, maxext / 60000.0);     // <= ~2^16 cells per axis
     if (force_h > 0) h = std::max(force_h, maxext / 60000.0);
   }
-  for (;;) {
-    const double inv_h = 1.0 / h;
+  const uint64_t cap = (uint64_t)(force_h > 0 ? c->refine_macros : PT_MAX_MACROS);
+  auto lay = [&](double hh) -> uint64_t {                 // grid of cell side hh; returns its number of macro blocks
+    const double inv_h = 1.0 / hh;
     uint64_t nmacro = 1;
     for (int a = 0; a < 3; ++a) {
       g.bbmin[a] = mn[a];
@@ -208,9 +210,19 @@ void choose_grid(pt_ctx* c, const double mn[3], const double mx[3], double force
       nmacro *= (uint64_t)g.mdim[a];
     }
     g.inv_h = inv_h;
-    g.h = h;
-    if (nmacro <= (uint64_t)(force_h > 0 ? c->refine_macros : PT_MAX_MACROS)) { g.nblocks = (int)(nmacro * PT_MACRO_BLOCKS); break; }
-    h *= 1.2599210498948732;   // too many macro blocks for the sort (and a cell table beyond 2^31 entries): double the cell volume
+    g.h = hh;
+    g.nblocks = (int)(std::min<uint64_t>(nmacro, PT_MAX_MACROS) * PT_MACRO_BLOCKS);
+    return nmacro;
+  };
+  c->grid_capped = false;
+  if (lay(h) > cap) {
+    // too many macro blocks for the sort (and a cell table beyond 2^31 entries): the FINEST grid that fits -- the occupancy-driven
+    // refinement would otherwise creep towards it in steps that cost a full sort each
+    c->grid_capped = true;
+    double lo = h, hi = h;                                 // lo does not fit, hi does
+    do { hi *= 1.2599210498948732; } while (lay(hi) > cap);
+    for (int it = 0; it < 12; ++it) { const double mid = std::sqrt(lo * hi); if (lay(mid) > cap) lo = mid; else hi = mid; }
+    (void)lay(hi);
   }
 }
 
