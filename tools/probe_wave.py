@@ -9,9 +9,12 @@ big = len(sys.argv) > 1 and sys.argv[1] == "c5"
 n, m, k, xt = (1_000_000_000, 50_000_000, 32, pkg.F16) if big else (100_000_000, 5_000_000, 8, pkg.F32)
 ref = None
 for spec in sys.argv[2:]:
-    thr, wmin = (int(v) for v in spec.split(":"))
+    parts = [int(v) for v in spec.split(":")]
+    thr, wmin, macros = parts[0], parts[1], (parts[2] if len(parts) > 2 else 0)
     with pkg.PointsTransfer(device=0, k_hint=k) as p:
         p.set_param("refine_threshold", thr); p.set_param("wave_min", wmin)
+        if macros:
+            p.set_param("refine_macros", macros)
         p.build_synth(n, 0xC5, dist=pkg.capi.DIST_CLUSTERED, xyz_type=xt); p.targets_synth(m, 0xC5, dist=pkg.capi.DIST_CLUSTERED, xyz_type=xt)
         idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
         for it in range(2):
@@ -22,5 +25,6 @@ for spec in sys.argv[2:]:
             ref = (idx.clone(), d2.clone())
         else:
             same = bool(torch.equal(idx, ref[0]) and torch.equal(d2, ref[1]))
+        print("macros %d grid %s " % (macros, st["grid_dim"]), end="")
         print("n %d k %d thr %d wave_min %d: build %.2f knn %.2f ms, wave targets %d, nodes %d, same=%s" %
               (n, k, thr, wmin, st["ms_build"], st["ms_query"], st["n_wave"], st["n_nodes"], same), flush=True)
