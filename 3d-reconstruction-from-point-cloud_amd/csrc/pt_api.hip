@@ -71,12 +71,13 @@ struct pt_ctx {
                                         // generator: beyond 1024 the extra sort pass costs more than the shorter scans save)
   bool grid_capped = false;             // the last choose_grid ran into the macro-block limit: no finer grid exists
   int wave_force = 0;                   // 1: the heavy / light split also on clouds without density contrast (tests, tuning)
-  uint32_t wave_min = 512;              // targets with at least this many points in their 27 nearest cells get a wave each (0: never)
+  uint32_t wave_min = 1;                // targets with at least this many points in their 27 nearest cells get a wave each (0: never; 1: all of
+                                        // them, and the group kernel is not run at all -- the default: 1B clustered / k=32 469 ms at 512, 448 at 1 before that shortcut)
   double refine_threshold = 8192.0;     // 0: never refine.  Measured on the clustered generator (tools/probe_wave.py) with the wave kernel taking the dense
                                         // neighbourhoods: a descent costs several dependent memory round trips, a scan of 64 records per step does
                                         // not, so only cells of many thousands of points are worth a sub-grid -- 1B / 50M / k = 32: 675 ms unrefined,
                                         // 585 / 565 / 553 / 554 at 2048 / 4096 / 8192 / 16384; 100M / 5M / k = 8: 20.3 / 22.1 / 21.9 / 21.2 / 21.1 ms
-  DevBuf cell_node, nodes;
+  DevBuf cell_node, nodes, near_node;   // near_node: one byte per cell, set for the 27 cells around every level-0 node
   uint32_t n_nodes = 0, refine_levels = 0;
   // slab exchange (pt_comm_* / pt_exchange_*)
   void* nccl_comm = nullptr;
@@ -368,10 +369,12 @@ int rebuild(pt_ctx* c) {
     const uint64_t cap64 = std::min<uint64_t>((uint64_t)PT_REFINE_DEPTH * (c->n / thr + 1) + 16, 0x7FFFFFF0ull / PT_NODE_WORDS * 8);
     const uint32_t cap = (uint32_t)std::min<uint64_t>(cap64, 64u << 20);
     RES(c, c->cell_node, (ncells + 1) * sizeof(uint32_t));
+    RES(c, c->near_node, ncells + 16);
+    HIPCHK(c, hipMemsetAsync(c->near_node.p, 0, ncells, c->stream));
     RES(c, c->nodes, (size_t)cap * PT_NODE_WORDS * sizeof(uint32_t));
     uint32_t* cnt = (uint32_t*)c->counter.p + 10;
     HIPCHK(c, hipMemsetAsync(cnt, 0, 4, c->stream));
-    pt_launch_heavy_cells(c->gp, (const uint32_t*)c->cell_start.p, (uint32_t)ncells, thr, (uint32_t*)c->cell_node.p, cnt, cap, (uint32_t*)c->nodes.p, c->stream);
+    pt_launch_heavy_cells(c->gp, (const uint32_t*)c->cell_start.p, (uint32_t)ncells, thr, (uint32_t*)c->cell_node.p, cnt, cap, (uint32_t*)c->nodes.p, (uint8_t*)c->near_node.p, c->stream);
     uint32_t n0 = 0, n1 = 0;
     for (int level = 0; level < PT_REFINE_DEPTH; ++level) {
       HIPCHK(c, hipMemcpyAsync(c->h_counter + 10, cnt, 4, hipMemcpyDeviceToHost, c->stream));
@@ -521,6 +524,30 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     return hipMemcpyAsync(hcnt, c->h_counter + 12, 8, hipMemcpyHostToDevice, c->stream) == hipSuccess;      // the kernels read their list length from the device
   };
   auto group_f32 = [&](const RecF* tg, const double* bnd, const uint32_t* list, const uint32_t* list_n) {
+    if (wave && c->wave_min <= 1) {
+      // every target gets a wave (measured on the clustered generator: the group kernel loses to it even on the sparse targets there,
+      // and marking 50 M targets costs it 70 ms): no group kernel at all.  Without refined cells the list is the input list;
+      // with them, a one-load-per-target pass marks who needs the descending variant.
+      if (!hier) {
+        uint32_t cnt = m;
+        if (list) {                                           // a device-side list (what the tile kernel left over): its length sizes the launch
+          if (hipMemcpyAsync(c->h_counter + 14, list_n, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return;
+          cnt = c->h_counter[14];
+        }
+        c->st.n_wave = cnt;
+        pt_launch_knn_wave<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, nullptr, nullptr, 0xFFFFFFFFu, tg, cnt, k, bnd, idx_dev, d2_dev, list, list_n, c->stream);
+        return;
+      }
+      (void)hipMemsetAsync(heavy, 0, m, c->stream);
+      pt_launch_mark_near<RecF>(c->gp, tg, list, list_n, m, (const uint8_t*)c->near_node.p, heavy, c->stream);
+      if (wave_lists()) {
+        pt_launch_knn_wave<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, nullptr, nullptr, 0xFFFFFFFFu, tg, c->h_counter[12], k, bnd, idx_dev, d2_dev,
+                                 hlist, hcnt, c->stream);
+        pt_launch_knn_wave<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const uint32_t*)c->cell_node.p, (const uint32_t*)c->nodes.p, (uint32_t)c->refine_threshold,
+                                 tg, c->h_counter[13], k, bnd, idx_dev, d2_dev, hlist + c->h_counter[12], hcnt + 1, c->stream);
+      }
+      return;
+    }
     if (wave) (void)hipMemsetAsync(heavy, 0, m, c->stream);
     if (hier) pt_launch_knn_hier<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const uint32_t*)c->cell_node.p, (const uint32_t*)c->nodes.p, (uint32_t)c->refine_threshold, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream, heavy, c->wave_min);
     else pt_launch_knn<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream, heavy, c->wave_min);
@@ -532,6 +559,30 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     }
   };
   auto group_f64 = [&](const RecD* tg, const double* bnd, const uint32_t* list, const uint32_t* list_n) {
+    if (wave && c->wave_min <= 1) {
+      // every target gets a wave (measured on the clustered generator: the group kernel loses to it even on the sparse targets there,
+      // and marking 50 M targets costs it 70 ms): no group kernel at all.  Without refined cells the list is the input list;
+      // with them, a one-load-per-target pass marks who needs the descending variant.
+      if (!hier) {
+        uint32_t cnt = m;
+        if (list) {                                           // a device-side list (what the tile kernel left over): its length sizes the launch
+          if (hipMemcpyAsync(c->h_counter + 14, list_n, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return;
+          cnt = c->h_counter[14];
+        }
+        c->st.n_wave = cnt;
+        pt_launch_knn_wave<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, nullptr, nullptr, 0xFFFFFFFFu, tg, cnt, k, bnd, idx_dev, d2_dev, list, list_n, c->stream);
+        return;
+      }
+      (void)hipMemsetAsync(heavy, 0, m, c->stream);
+      pt_launch_mark_near<RecD>(c->gp, tg, list, list_n, m, (const uint8_t*)c->near_node.p, heavy, c->stream);
+      if (wave_lists()) {
+        pt_launch_knn_wave<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, nullptr, nullptr, 0xFFFFFFFFu, tg, c->h_counter[12], k, bnd, idx_dev, d2_dev,
+                                 hlist, hcnt, c->stream);
+        pt_launch_knn_wave<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, (const uint32_t*)c->cell_node.p, (const uint32_t*)c->nodes.p, (uint32_t)c->refine_threshold,
+                                 tg, c->h_counter[13], k, bnd, idx_dev, d2_dev, hlist + c->h_counter[12], hcnt + 1, c->stream);
+      }
+      return;
+    }
     if (wave) (void)hipMemsetAsync(heavy, 0, m, c->stream);
     if (hier) pt_launch_knn_hier<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, (const uint32_t*)c->cell_node.p, (const uint32_t*)c->nodes.p, (uint32_t)c->refine_threshold, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream, heavy, c->wave_min);
     else pt_launch_knn<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, tg, m, k, bnd, idx_dev, d2_dev, list, list_n, c->stream, heavy, c->wave_min);
@@ -668,7 +719,7 @@ void pt_ctx_destroy(pt_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in_xyz, &c->in_gidx, &c->attr, &c->rec, &c->rec_tmp, &c->cell_start, &c->stb_mem, &c->t_xyz, &c->t_gidx, &c->trec,
                    &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr, &c->retry, &c->rec32, &c->up_rgb, &c->up_nrm, &c->x_bounds, &c->x_counts, &c->x_matrix, &c->x_off, &c->x_req, &c->x_row, &c->x_rreq,
-                   &c->x_rxyz, &c->x_rbound, &c->x_ans_i, &c->x_ans_d, &c->x_back_i, &c->x_back_d, &c->x_flags, &c->x_rows, &c->cell_node, &c->nodes, &c->heavy};
+                   &c->x_rxyz, &c->x_rbound, &c->x_ans_i, &c->x_ans_d, &c->x_back_i, &c->x_back_d, &c->x_flags, &c->x_rows, &c->cell_node, &c->nodes, &c->heavy, &c->near_node};
   for (DevBuf* b : all) release(c, *b);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);

@@ -71,6 +71,9 @@ void pt_launch_knn(const GridParams& gp, const Rec* src, const uint32_t* cell_st
 void pt_launch_mark_count(const uint8_t* mark, uint32_t m, uint32_t* off1, uint32_t* off2, uint32_t* scan_tmp, hipStream_t s);   // off*: [tiles + 1], totals last
 void pt_launch_mark_write(const uint8_t* mark, uint32_t m, const uint32_t* off1, const uint32_t* off2, uint32_t* list1, uint32_t* list2, hipStream_t s);
 uint32_t pt_mark_tiles(uint32_t m);
+// the marks without the group kernel: every listed target (list == null: all m) gets 1, or 2 when its own cell carries the `near` flag
+template <class Rec>
+void pt_launch_mark_near(const GridParams& gp, const Rec* tgt, const uint32_t* list, const uint32_t* list_n, uint32_t m, const uint8_t* near, uint8_t* mark, hipStream_t s);
 // quad-per-target LDS tile kernel (fp32 records, k <= 32); leftovers go to todo[*todo_n] and are finished by pt_launch_knn(list=todo)
 // staged-region capacities (records) of the tile kernel's geometries: what is left of 80 KB (two workgroups per CU) or
 // 160 KB (one) after the per-lane queue segments and the cell table
@@ -150,7 +153,7 @@ void pt_launch_blend_rows(const uint32_t* rows, const uint32_t* rows_n, uint32_t
 // ---- pt_refine.hip ------------------------------------------------------------------------------
 // cells with more than `threshold` points become nodes (cell_node[c] = node id + 1, else 0; *node_count counts them, also past node_cap)
 void pt_launch_heavy_cells(const GridParams& gp, const uint32_t* cs, uint32_t ncells, uint32_t threshold, uint32_t* cell_node, uint32_t* node_count,
-                           uint32_t node_cap, uint32_t* nodes, hipStream_t s);
+                           uint32_t node_cap, uint32_t* nodes, uint8_t* near_or_null, hipStream_t s);   // near: one zeroed byte per cell, set for the 27 cells around every node
 // the same one level down for the nodes [n0, n1) (their tables must be built); threshold 0xFFFFFFFF just clears the child tables
 void pt_launch_heavy_subcells(uint32_t n0, uint32_t n1, uint32_t threshold, uint32_t* node_count, uint32_t node_cap, uint32_t* nodes, hipStream_t s);
 // counting sort of the records of the nodes [n0, n1) by sub-cell, in place (tmp: scratch of the same size as rec), + their start tables

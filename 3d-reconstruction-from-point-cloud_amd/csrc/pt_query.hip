@@ -1741,6 +1741,25 @@ __global__ __launch_bounds__(WG) void mark_write_kernel(const uint8_t* __restric
     else if (v[i] == 2u) list2[eb++] = t;
   }
 }
+template <class Rec>
+__global__ __launch_bounds__(WG) void mark_near_kernel(GridParams gp, const Rec* __restrict__ tgt, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_n,
+                                                       uint32_t m, const uint8_t* __restrict__ near, uint8_t* __restrict__ mark) {
+  const uint32_t i = blockIdx.x * WG + threadIdx.x;
+  if (i >= (list ? *list_n : m)) return;
+  const uint32_t pos = list ? list[i] : i;
+  const Rec r = tgt[pos];
+  const double q[3] = {(double)r.x, (double)r.y, (double)r.z};
+  int c[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) c[a] = (int)fmin(fmax((q[a] - gp.bbmin[a]) * gp.inv_h, 0.0), (double)(gp.dim[a] - 1));     // as the search kernels place the target
+  mark[pos] = near[cell_key(gp, c[0], c[1], c[2])] ? 2u : 1u;
+}
+template <class Rec>
+void pt_launch_mark_near(const GridParams& gp, const Rec* tgt, const uint32_t* list, const uint32_t* list_n, uint32_t m, const uint8_t* near, uint8_t* mark, hipStream_t s) {
+  if (m) hipLaunchKernelGGL(mark_near_kernel<Rec>, dim3((m + WG - 1) / WG), dim3(WG), 0, s, gp, tgt, list, list_n, m, near, mark);
+}
+template void pt_launch_mark_near<RecF>(const GridParams&, const RecF*, const uint32_t*, const uint32_t*, uint32_t, const uint8_t*, uint8_t*, hipStream_t);
+template void pt_launch_mark_near<RecD>(const GridParams&, const RecD*, const uint32_t*, const uint32_t*, uint32_t, const uint8_t*, uint8_t*, hipStream_t);
 // counts -> cnt[nt + 1] each (exclusive offsets, the totals in the last entry); scratch: 2 * (nt + 1) + scan scratch words
 void pt_launch_mark_count(const uint8_t* mark, uint32_t m, uint32_t* off1, uint32_t* off2, uint32_t* scan_tmp, hipStream_t s) {
   const uint32_t nt = (m + CP_TILE - 1) / CP_TILE;

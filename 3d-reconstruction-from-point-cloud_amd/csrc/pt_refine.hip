@@ -26,9 +26,11 @@ __device__ inline void node_header(uint32_t* node, double ox, double oy, double 
 }
 
 // level 0: every cell with more than `threshold` points becomes a node
+// (near, optional, one zeroed byte per cell: the 27 cells around every node are flagged -- a target whose own cell carries the flag
+//  has a refined cell among its 27 nearest, which is all the search needs to know to pick the kernel variant for it)
 __global__ __launch_bounds__(256) void heavy_cells_kernel(GridParams gp, const uint32_t* __restrict__ cs, uint32_t ncells, uint32_t threshold,
                                                           uint32_t* __restrict__ cell_node, uint32_t* __restrict__ node_count, uint32_t node_cap,
-                                                          uint32_t* __restrict__ nodes) {
+                                                          uint32_t* __restrict__ nodes, uint8_t* __restrict__ near) {
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;
   if (c >= ncells) return;
   const uint32_t s = cs[c], e = cs[c + 1];
@@ -40,6 +42,15 @@ __global__ __launch_bounds__(256) void heavy_cells_kernel(GridParams gp, const u
       pt_decode_cell(gp, c, cx, cy, cz);
       node_header(nodes + (size_t)slot * PT_NODE_WORDS, (double)cx, (double)cy, (double)cz, 8.0, s, e);
       id = slot + 1;
+      if (near) {
+        for (int dz = -1; dz <= 1; ++dz)
+          for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+              const int x = cx + dx, y = cy + dy, z = cz + dz;
+              if (x >= 0 && x < gp.dim[0] && y >= 0 && y < gp.dim[1] && z >= 0 && z < gp.dim[2])
+                near[(pt_block_id(gp.mdim, x, y, z) << 9) + pt_local_cell(x, y, z)] = 1;
+            }
+      }
     }
   }
   cell_node[c] = id;
@@ -150,9 +161,9 @@ __global__ __launch_bounds__(256) void reshadow_kernel(const RecD* __restrict__ 
 }  // namespace
 
 void pt_launch_heavy_cells(const GridParams& gp, const uint32_t* cs, uint32_t ncells, uint32_t threshold, uint32_t* cell_node, uint32_t* node_count,
-                           uint32_t node_cap, uint32_t* nodes, hipStream_t s) {
+                           uint32_t node_cap, uint32_t* nodes, uint8_t* near, hipStream_t s) {
   if (!ncells) return;
-  hipLaunchKernelGGL(heavy_cells_kernel, dim3((ncells + 255) / 256), dim3(256), 0, s, gp, cs, ncells, threshold, cell_node, node_count, node_cap, nodes);
+  hipLaunchKernelGGL(heavy_cells_kernel, dim3((ncells + 255) / 256), dim3(256), 0, s, gp, cs, ncells, threshold, cell_node, node_count, node_cap, nodes, near);
 }
 void pt_launch_heavy_subcells(uint32_t n0, uint32_t n1, uint32_t threshold, uint32_t* node_count, uint32_t node_cap, uint32_t* nodes, hipStream_t s) {
   if (n1 <= n0) return;

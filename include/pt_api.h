@@ -112,7 +112,7 @@ int  pt_set_stream(pt_ctx*, void* hip_stream);
  * "refine_threshold" (grid cells holding more points than this get an 8x8x8 sub-grid, recursively up to three levels, which
  * searches descend into instead of scanning the cell end to end -- clouds with strong density contrast; default 8192, 0 = never),
  * "wave_min" (on such clouds a target whose 27 nearest cells hold at least this many points is answered by a whole wave instead of
- * an 8-lane group; default 512, 0 = never; "wave_force" = 1 applies that split to every cloud -- a testing hook), "refine_macros"
+ * an 8-lane group; default 1 = every target of such a cloud, 0 = never; "wave_force" = 1 applies that split to every cloud -- a testing hook), "refine_macros"
  * (the finest grid the refinement of the cell size may ask for, in 64^3-cell macro blocks: default 1024, at most 8192 -- grids beyond
  * 1024 macro blocks, which a cloud of more than ~1e9 points gets anyway, cost the sort one more partition pass). */
 int  pt_set_param(pt_ctx*, const char* name, double value);

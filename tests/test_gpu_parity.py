@@ -1114,10 +1114,11 @@ def test_refined_cells_are_exact(pkg, oracle, kind, k, f64, thr):
         _check_exact(p.query(tgt, k), want, "unrefined %s" % kind)
 
 
-@pytest.mark.parametrize("kind,k,f64,thr,rho", [("blobs", 8, False, 0, None), ("blobs", 32, True, 48, None), ("sheet", 20, False, 3, None), ("lattice", 8, False, 0, None),
-                                                ("lattice", 32, False, 32, None), ("line", 16, True, 3, None), ("uniform", 32, False, 0, 0.4), ("uniform", 8, True, 0, None)])
-def test_wave_kernel_is_exact(pkg, oracle, kind, k, f64, thr, rho):
-    """One wave per target (knn_wave_kernel), forced for every target with a single point in its 27 nearest cells: dense cells,
+@pytest.mark.parametrize("kind,k,f64,thr,rho,wmin", [("blobs", 8, False, 0, None, 1), ("blobs", 32, True, 48, None, 1), ("sheet", 20, False, 3, None, 2), ("lattice", 8, False, 0, None, 2),
+                                                     ("lattice", 32, False, 32, None, 1), ("line", 16, True, 3, None, 1), ("uniform", 32, False, 0, 0.4, 1), ("uniform", 8, True, 0, None, 2),
+                                                     ("blobs", 20, False, 24, None, 2)])
+def test_wave_kernel_is_exact(pkg, oracle, kind, k, f64, thr, rho, wmin):
+    """One wave per target (knn_wave_kernel), forced for every target (or every target with two points in its 27 nearest cells): dense cells,
     refined cells (thr > 0: descended into, 64 rows per step), sparse neighbourhoods that need several shells (rho 0.4 at k = 32), a
     target next to a lone outlier (block sweep), radius-bounded queries -- all equal to brute force bit for bit."""
     import torch
@@ -1134,7 +1135,8 @@ def test_wave_kernel_is_exact(pkg, oracle, kind, k, f64, thr, rho):
         src = src.astype(np.float64) + (rng.random(src.shape) - 0.5) * 1e-9 * (kind != "lattice"); tgt = tgt.astype(np.float64)
     want = oracle.knn_bruteforce(src, tgt, k)
     with pkg.PointsTransfer(device=0, k_hint=min(k, 32), rho=rho) as p:
-        p.set_param("refine_threshold", thr); p.set_param("tile", 0); p.set_param("wave_force", 1); p.set_param("wave_min", 1)
+        # wave_min 1: no group kernel at all (targets next to refined cells found by the per-cell flag); 2: the group kernel marks the targets
+        p.set_param("refine_threshold", thr); p.set_param("tile", 0); p.set_param("wave_force", 1); p.set_param("wave_min", wmin)
         p.build(src)
         st = p.stats()
         assert (st["n_nodes"] > 0) == (thr > 0), st
