@@ -624,7 +624,7 @@ __global__ __launch_bounds__(WG, HIER ? (KPL == 4 ? 3 : 4) : 1) void knn_kernel(
 // limit is a scalar.  Cells, shells, blocks and the rows of refined nodes are looked up 64 at a time, one per lane.
 // Same order, same bounds, same results as the group kernel (exact); k <= 64.
 constexpr int DPP_WAVE_SHR1 = 0x138;     // wave_shr:1: lane i <- lane i - 1 across the wave (lane 0 reads 0)
-constexpr int WV_RING_MAX = 31;          // a shell row (2 r + 1 cells) must fit the 64 lanes
+constexpr int WV_RING_MAX = 31;          // shells are walked up to this ring at most (then the blocks are swept)
 constexpr uint32_t WV_RUN = 16;          // consecutive workgroups (64 targets) that share an XCD
 
 // key_lt without short-circuit evaluation: no branches around the comparisons (the compiler turns `a < b || (a == b && i < j)` on
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams g
   };
   const int ring_limit = min(WV_RING_MAX, max(PT_RING_LIMIT, (int)cbrtf(0.07f * (float)gp.nblocks)));
   // One loop serves ring 1 (27 cells, the target's own first, then its row, then the rest centre-first) and every further shell
-  // (step by step: a row or a column of the shell's cells per step), so that the scan and the descent exist once in the code.
+  // (64 of its cells per step), so that the scan and the descent exist once in the code.
   int rr = 1, st = -1, nst = 0;
   for (;;) {
     int x = 0, y = 0, z = 0;
@@ -921,18 +921,20 @@ __global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams g
       valid = lane < 27;
       x = c[0] + (j == 0 ? 0 : (j == 1 ? -1 : 1)); y = c[1] + row_dy(valid ? r : 0); z = c[2] + row_dz(valid ? r : 0);
     } else {
-      const int side = 2 * rr + 1;
+      // cell i of the shell of ring rr (side^3 - (side - 2)^3 of them), 64 per step: the two full planes dz = -rr, +rr row by row, then
+      // for every plane in between its perimeter -- row dy = -rr, row dy = +rr, column dx = -rr, column dx = +rr
+      const uint32_t side = 2u * (uint32_t)rr + 1u, in = side - 2u, plane = side * side, per = 4u * side - 4u;
+      const uint32_t i = (uint32_t)st * 64u + (uint32_t)lane;
+      valid = i < 2u * plane + in * per;
       int dx, dy, dz;
-      if (st < 2 * side) {                                  // the two full planes dz = -rr, +rr: a row of them per step, lanes along x
-        dz = st < side ? -rr : rr;
-        dy = -rr + (st < side ? st : st - side);
-        dx = -rr + lane;
-        valid = lane < side;
-      } else {                                              // planes in between: the perimeter, two rows (lanes along x) and two columns (lanes along y)
-        const int t = st - 2 * side, pz = t >> 2, kind = t & 3;
-        dz = -rr + 1 + pz;
-        if (kind < 2) { dy = kind ? rr : -rr; dx = -rr + lane; valid = lane < side; }
-        else { dx = kind == 3 ? rr : -rr; dy = -rr + 1 + lane; valid = lane < side - 2; }
+      if (i < 2u * plane) {
+        const uint32_t j = i < plane ? i : i - plane, row = j / side;
+        dz = i < plane ? -rr : rr; dy = (int)row - rr; dx = (int)(j - row * side) - rr;
+      } else {
+        const uint32_t j = i - 2u * plane, pz = j / per, q = j - pz * per;
+        dz = -rr + 1 + (int)pz;
+        if (q < 2u * side) { dy = q < side ? -rr : rr; dx = (int)(q < side ? q : q - side) - rr; }
+        else { const uint32_t t = q - 2u * side; dx = t < in ? -rr : rr; dy = -rr + 1 + (int)(t < in ? t : t - in); }
       }
       x = c[0] + dx; y = c[1] + dy; z = c[2] + dz;
     }
@@ -1003,7 +1005,7 @@ __global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams g
     }
     ++rr;
     st = 0;
-    nst = 2 * (2 * rr + 1) + 4 * (2 * rr - 1);
+    { const int side = 2 * rr + 1; nst = (side * side * side - (side - 2) * (side - 2) * (side - 2) + 63) / 64; }
   }
   if (lane < k) {
     const size_t row = (size_t)tr.id * (size_t)k;
