@@ -69,6 +69,10 @@ struct pt_ctx {
   // refinement of heavy cells (pt_refine.hip): sub-grids inside cells with more than refine_threshold points
   int refine_macros = PT_MAXBINS;       // finest grid the occupancy-driven refinement of h may ask for, in macro blocks (measured on the clustered
                                         // generator: beyond 1024 the extra sort pass costs more than the shorter scans save)
+  // rebuilds of the SAME resident cloud (pt_rebuild) start from the cell size the last build ended with instead of searching for it again
+  // (a refined grid costs one full sort per step of the search); the occupancy finalize reports checks the guess, a new cloud resets it
+  double hint_h = 0.0, hint_rho_occ = 0.0;
+  int hint_refines = 0, grid_hint = 1;
   bool grid_capped = false;             // the last choose_grid ran into the macro-block limit: no finer grid exists
   int wave_force = 0;                   // 1: the heavy / light split also on clouds without density contrast (tests, tuning)
   uint32_t wave_min = 1;                // targets with at least this many points in their 27 nearest cells get a wave each (0: never; 1: all of
@@ -282,6 +286,8 @@ int rebuild(pt_ctx* c) {
   // those hold far more than rho points each (surfaces, clusters) the cell size is refined -- at most three times, and never
   // beyond what the dense cell table allows (choose_grid coarsens again if the macro-block limit is hit).
   double force_h = 0.0;
+  bool hinted = false;
+  if (c->grid_hint && c->adaptive && c->hint_h > 0.0) { force_h = c->hint_h; hinted = true; }
   uint32_t nblocks = 0;
   size_t ncells = 0;
   c->st.n_refine = 0;
@@ -349,6 +355,11 @@ int rebuild(pt_ctx* c) {
     const double occupied = std::max<double>(1.0, c->h_counter[8]);
     max_cell = c->h_counter[9];
     c->st.rho_occupied = (double)c->n / occupied;
+    if (hinted) {
+      if (c->st.rho_occupied <= 1.25 * c->hint_rho_occ) { c->st.n_refine = c->hint_refines; break; }     // the grid the last build settled on still fits
+      hinted = false; c->hint_h = 0.0; force_h = 0.0; c->st.n_refine = 0; iter = -1;                      // it does not (the resident cloud was changed under us): search again
+      continue;
+    }
     if (iter >= 3 || c->st.rho_occupied <= 1.5 * c->rho) break;
     const double h_old = c->gp.h;
     const int d0 = c->gp.dim[0], d1 = c->gp.dim[1], d2 = c->gp.dim[2];
@@ -361,6 +372,7 @@ int rebuild(pt_ctx* c) {
     if (!changed || !finer) break;                 // already at the resolution limit (or nothing left to split)
     ++c->st.n_refine;
   }
+  if (c->st.n_refine > 0 && !hinted) { c->hint_h = c->gp.h; c->hint_rho_occ = c->st.rho_occupied; c->hint_refines = c->st.n_refine; }
   // ---- heavy cells get sub-grids (pt_refine.hip): only clouds whose fullest cell is over the threshold pay anything here ----
   c->n_nodes = 0; c->refine_levels = 0;
   if (c->refine_threshold >= 1.0 && c->adaptive && c->n && (double)max_cell > c->refine_threshold) {
@@ -740,6 +752,7 @@ int pt_set_stream(pt_ctx* c, void* hip_stream) {
 
 int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!c || !name) return PT_ERR_ARG;
+  c->hint_h = 0.0;                     // (whatever changes, the next build searches its cell size afresh)
   if (!strcmp(name, "rho")) { if (!(value >= 1e-4 && value <= 4096)) return fail(c, PT_ERR_ARG, "rho out of range"); c->rho = value; return PT_OK; }
   if (!strcmp(name, "k_hint")) {
     // cell density for the k the caller is going to ask for: ring 1 (3x3x3 cells) must usually contain the k nearest
@@ -753,6 +766,7 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!strcmp(name, "sync")) { c->sync = value != 0; return PT_OK; }
   if (!strcmp(name, "adaptive")) { c->adaptive = value != 0; return PT_OK; }
   if (!strcmp(name, "tile")) { c->tile = (int)value; return PT_OK; }
+  if (!strcmp(name, "grid_hint")) { c->grid_hint = value != 0; if (!c->grid_hint) c->hint_h = 0.0; return PT_OK; }
   if (!strcmp(name, "refine_macros")) { if (!(value >= 1 && value <= PT_MAX_MACROS)) return fail(c, PT_ERR_ARG, "refine_macros out of range"); c->refine_macros = (int)value; return PT_OK; }
   if (!strcmp(name, "wave_force")) { c->wave_force = value != 0; return PT_OK; }
   if (!strcmp(name, "wave_min")) { if (!(value >= 0 && value <= 4e9)) return fail(c, PT_ERR_ARG, "wave_min out of range"); c->wave_min = (uint32_t)value; return PT_OK; }
@@ -792,7 +806,7 @@ int pt_build_aos(pt_ctx* c, const pt_point* cloud, uint64_t n) {
   { int r = copy_in(c, c->aos_stage.p, cloud, n * sizeof(pt_point), 0); if (r) return r; }
   double* x = (double*)c->in_xyz.p;
   pt_launch_aos_split(c->aos_stage.p, (uint32_t)n, x, x + n, x + 2 * n, (Attr*)c->attr.p, c->stream);
-  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true;
+  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0;
   return rebuild(c);
 }
 
@@ -807,7 +821,7 @@ int pt_build_soa_indexed(pt_ctx* c, const void* xyz, int xyz_type, const uint32_
   }
   c->src_type = xyz_type; c->n = n; c->has_gidx = gidx != nullptr; c->built = false;
   if (!gidx) { c->n_total = n; c->has_attr = false; }
-  c->posattr_valid = false; c->bbox_guess_ok = true;
+  c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0;
   return rebuild(c);
 }
 
@@ -863,7 +877,7 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
   else { double* x = (double*)c->in_xyz.p; pt_launch_synth_xyz<double>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream); }
   RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
   pt_launch_synth_attr(seed, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
-  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true;
+  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0;
   return rebuild(c);
 }
 
@@ -1238,7 +1252,7 @@ int pt_upload_end(pt_ctx* c) {
   if (c->up_attr) pt_launch_pack_attr((const uint8_t*)c->up_rgb.p, (const float*)c->up_nrm.p, (uint32_t)n, (Attr*)c->attr.p, c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));                                // the caller's buffers are free again
   c->src_type = c->up_type; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = c->up_attr != 0; c->built = false;
-  c->posattr_valid = false; c->bbox_guess_ok = true;
+  c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0;
   c->up_type = -1;
   release(c, c->up_rgb); release(c, c->up_nrm);
   return rebuild(c);
@@ -1303,7 +1317,7 @@ int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64
       HIPCHK(c, hipStreamWaitEvent(c->stream, copied[b], 0));
       c->in_xyz = stage[b];
       c->src_type = xyz_type; c->n = cnt; c->n_total = cnt; c->has_gidx = false; c->has_attr = false; c->built = false;
-      c->posattr_valid = false; c->bbox_guess_ok = true;
+      c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0;
       { int r = rebuild(c); if (r) return r; }
       HIPCHK(c, hipEventRecord(consumed[b], c->stream));               // the build no longer reads stage[b] (records hold the coordinates)
       { int r = run_query(c, c->t_xyz.p, c->tgt_type, m, k, nullptr, (uint32_t*)ci.p, (double*)cd.p); if (r) return r; }

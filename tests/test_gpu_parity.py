@@ -689,6 +689,8 @@ def test_sampled_bounding_box_and_its_fallback(pkg, oracle):
     tgt = oracle.synth_xyz(seed, 1, m)
     with pkg.PointsTransfer(device=0, rho=0.5) as p:          # rho 0.5: enough blocks for the two-level (chunked) sort
         p.set_param("guess_min_points", 100000)
+        p.set_param("grid_hint", 0)                            # (at rho 0.5 even a uniform cloud gets its cell size refined; a rebuild that starts from the
+                                                               #  remembered size lays out a grid without room for the guess -- not what this test is about)
         p.build(src)
         assert p.stats()["bbox_guess"] == 1 and p.stats()["n_levels"] == 2
         _check_exact(p.query(tgt, k), oracle.KdTree(src).query(tgt, k), "sampled box accepted")
@@ -1174,6 +1176,28 @@ def test_three_level_sort_for_very_fine_grids(pkg, oracle, kind, f64):
             st = p.stats()
             assert st["n_levels"] == 3, st
             _check_exact(p.query(tgt, k), want, "three-level %s tile=%d" % (kind, tile))
+
+
+def test_rebuild_starts_from_the_remembered_cell_size(pkg, oracle):
+    """pt_rebuild of the same resident cloud: the cell size the first build searched for (refinement steps, one full sort each) is where
+    the rebuild starts, checked against the occupancy it finds; results identical; a new cloud in the same context searches again."""
+    from test_gpu_stress import _cloud
+    rng = np.random.default_rng(5)
+    src = _cloud(rng, "blobs", 200000); tgt = _cloud(rng, "blobs", 2000)
+    want = oracle.knn_bruteforce(src, tgt, 8)
+    with pkg.PointsTransfer(device=0, k_hint=8) as p:
+        p.build(src)
+        st0 = p.stats()
+        assert st0["n_refine"] >= 1
+        _check_exact(p.query(tgt, 8), want, "first build")
+        p.rebuild()
+        st1 = p.stats()
+        assert st1["grid_dim"] == st0["grid_dim"] and st1["n_refine"] == st0["n_refine"]
+        _check_exact(p.query(tgt, 8), want, "rebuild from the remembered cell size")
+        uni = rng.random((3, 150000), dtype=np.float32)
+        p.build(uni)                                          # another cloud: no hint
+        assert p.stats()["n_refine"] == 0
+        _check_exact(p.query(tgt, 8), oracle.knn_bruteforce(uni, tgt, 8), "new cloud")
 
 
 def test_full_size_clustered_sampled_against_oracle(pkg, oracle):
