@@ -526,6 +526,12 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     heavy = (uint8_t*)(hscan + mtiles + 4);
   }
   c->st.n_wave = 0;
+  bool wave_blended = false;       // the wave kernel answered every target this call was about AND blended it: no blend pass afterwards
+  const Attr* wattr = br ? (const Attr*)c->attr.p : nullptr;
+  const uint32_t wnattr = (uint32_t)c->n_total;
+  const int wmode = br ? br->mode : 0;
+  float* wrgb = br ? br->rgb_out : nullptr;
+  float* wnrm = br ? br->nrm_out : nullptr;
   // marks -> ordered lists; one read-back of the two lengths.  false: a HIP call failed (the caller's hipGetLastError reports it)
   auto wave_lists = [&]() -> bool {
     pt_launch_mark_count(heavy, m, hoff1, hoff2, hscan, c->stream);
@@ -548,16 +554,19 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
           cnt = c->h_counter[14];
         }
         c->st.n_wave = cnt;
-        pt_launch_knn_wave<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, nullptr, nullptr, 0xFFFFFFFFu, tg, cnt, k, bnd, idx_dev, d2_dev, list, list_n, c->stream);
+        pt_launch_knn_wave<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, nullptr, nullptr, 0xFFFFFFFFu, tg, cnt, k, bnd, idx_dev, d2_dev, list, list_n, c->stream,
+                                 wattr, wnattr, wmode, wrgb, wnrm);
+        wave_blended = true;
         return;
       }
       (void)hipMemsetAsync(heavy, 0, m, c->stream);
       pt_launch_mark_near<RecF>(c->gp, tg, list, list_n, m, (const uint8_t*)c->near_node.p, heavy, c->stream);
       if (wave_lists()) {
         pt_launch_knn_wave<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, nullptr, nullptr, 0xFFFFFFFFu, tg, c->h_counter[12], k, bnd, idx_dev, d2_dev,
-                                 hlist, hcnt, c->stream);
+                                 hlist, hcnt, c->stream, wattr, wnattr, wmode, wrgb, wnrm);
         pt_launch_knn_wave<RecF>(c->gp, (const RecF*)c->rec.p, (const uint32_t*)c->cell_start.p, (const uint32_t*)c->cell_node.p, (const uint32_t*)c->nodes.p, (uint32_t)c->refine_threshold,
-                                 tg, c->h_counter[13], k, bnd, idx_dev, d2_dev, hlist + c->h_counter[12], hcnt + 1, c->stream);
+                                 tg, c->h_counter[13], k, bnd, idx_dev, d2_dev, hlist + c->h_counter[12], hcnt + 1, c->stream, wattr, wnattr, wmode, wrgb, wnrm);
+        wave_blended = true;                                // (every marked target is on one of the two lists)
       }
       return;
     }
@@ -583,16 +592,19 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
           cnt = c->h_counter[14];
         }
         c->st.n_wave = cnt;
-        pt_launch_knn_wave<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, nullptr, nullptr, 0xFFFFFFFFu, tg, cnt, k, bnd, idx_dev, d2_dev, list, list_n, c->stream);
+        pt_launch_knn_wave<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, nullptr, nullptr, 0xFFFFFFFFu, tg, cnt, k, bnd, idx_dev, d2_dev, list, list_n, c->stream,
+                                 wattr, wnattr, wmode, wrgb, wnrm);
+        wave_blended = true;
         return;
       }
       (void)hipMemsetAsync(heavy, 0, m, c->stream);
       pt_launch_mark_near<RecD>(c->gp, tg, list, list_n, m, (const uint8_t*)c->near_node.p, heavy, c->stream);
       if (wave_lists()) {
         pt_launch_knn_wave<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, nullptr, nullptr, 0xFFFFFFFFu, tg, c->h_counter[12], k, bnd, idx_dev, d2_dev,
-                                 hlist, hcnt, c->stream);
+                                 hlist, hcnt, c->stream, wattr, wnattr, wmode, wrgb, wnrm);
         pt_launch_knn_wave<RecD>(c->gp, (const RecD*)c->rec.p, (const uint32_t*)c->cell_start.p, (const uint32_t*)c->cell_node.p, (const uint32_t*)c->nodes.p, (uint32_t)c->refine_threshold,
-                                 tg, c->h_counter[13], k, bnd, idx_dev, d2_dev, hlist + c->h_counter[12], hcnt + 1, c->stream);
+                                 tg, c->h_counter[13], k, bnd, idx_dev, d2_dev, hlist + c->h_counter[12], hcnt + 1, c->stream, wattr, wnattr, wmode, wrgb, wnrm);
+        wave_blended = true;                                // (every marked target is on one of the two lists)
       }
       return;
     }
@@ -615,13 +627,13 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     if (use_tile) {
       { int r = tile_launches((const RecF*)c->rec.p, tsorted, nullptr, nullptr, todo_n); if (r != PT_OK) return r; }
       group_f32(tsorted, nullptr, (const uint32_t*)c->todo.p, todo_n);
-      if (br)   // the targets the tile kernel handed over get their blend from the lists the group kernel just wrote
+      if (br && !wave_blended)   // the targets the tile kernel handed over get their blend from the lists the group kernel just wrote
         pt_launch_blend_list<RecF>((const uint32_t*)c->todo.p, todo_n, m, tsorted, idx_dev, d2_dev, k, br->mode, (const Attr*)c->attr.p,
                                    (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
       HIPCHK(c, hipMemcpyAsync(c->h_counter + 4, todo_n, 4, hipMemcpyDeviceToHost, c->stream));
     } else {
       group_f32(tsorted, bound2_dev, nullptr, nullptr);
-      if (br) pt_launch_blend(idx_dev, d2_dev, m, k, br->mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
+      if (br && !wave_blended) pt_launch_blend(idx_dev, d2_dev, m, k, br->mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
     }
   } else {
     const double* x = (const double*)txyz;
@@ -631,13 +643,13 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     if (use_tile) {
       { int r = tile_launches((const RecF*)c->rec32.p, nullptr, (const RecD*)c->rec.p, tsorted, todo_n); if (r != PT_OK) return r; }
       group_f64(tsorted, nullptr, (const uint32_t*)c->todo.p, todo_n);
-      if (br)
+      if (br && !wave_blended)
         pt_launch_blend_list<RecD>((const uint32_t*)c->todo.p, todo_n, m, tsorted, idx_dev, d2_dev, k, br->mode, (const Attr*)c->attr.p,
                                    (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
       HIPCHK(c, hipMemcpyAsync(c->h_counter + 4, todo_n, 4, hipMemcpyDeviceToHost, c->stream));
     } else {
       group_f64(tsorted, bound2_dev, nullptr, nullptr);
-      if (br) pt_launch_blend(idx_dev, d2_dev, m, k, br->mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
+      if (br && !wave_blended) pt_launch_blend(idx_dev, d2_dev, m, k, br->mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
     }
   }
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));

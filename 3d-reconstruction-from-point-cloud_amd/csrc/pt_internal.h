@@ -170,4 +170,5 @@ void pt_launch_knn_hier(const GridParams& gp, const Rec* src, const uint32_t* ce
 template <class Rec>
 void pt_launch_knn_wave(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const uint32_t* cell_node, const uint32_t* nodes, uint32_t node_thr,
                         const Rec* tgt, uint32_t count, int k, const double* bound2, uint32_t* out_idx, double* out_d2, const uint32_t* list,
-                        const uint32_t* list_n, hipStream_t s);
+                        const uint32_t* list_n, hipStream_t s, const Attr* attr = nullptr, uint32_t n_attr = 0, int blend_mode = 0, float* rgb_out = nullptr,
+                        float* nrm_out = nullptr);   // attr != null: the neighbours' attributes are blended in the same launch (rows of these targets only)

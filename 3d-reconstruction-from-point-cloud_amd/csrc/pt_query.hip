@@ -357,6 +357,8 @@ struct RowPlan {
 // position in the sorted target array) for the wave kernel below -- one wave per target pays off where the scans are long.
 // heavy: one byte per target position, zeroed by the caller; 1 = wave kernel, 2 = its descending variant (a refined cell among the 27).
 struct HierArgs { const uint32_t* cell_node; const uint32_t* nodes; uint32_t thr; uint8_t* heavy; uint32_t wave_min; };
+// attribute blend fused into the wave kernel (attr == null: none): the table, its length, the mode and the two outputs
+struct WaveBlend { const Attr* attr; uint32_t n_attr; int mode; float* rgb_out; float* nrm_out; };
 template <class Rec, int KPL, bool HIER>
 __global__ __launch_bounds__(WG, HIER ? (KPL == 4 ? 3 : 4) : 1) void knn_kernel(GridParams gp, const Rec* __restrict__ src, const uint32_t* __restrict__ cs,
                                                  const Rec* __restrict__ tgt, uint32_t m, int k, const double* __restrict__ bound2,
@@ -881,7 +883,7 @@ template <class Rec, bool HIER>
 __global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams gp, const Rec* __restrict__ src, const uint32_t* __restrict__ cs, const Rec* __restrict__ tgt,
                                                       uint32_t m, int k, const double* __restrict__ bound2, uint32_t* __restrict__ out_idx,
                                                       double* __restrict__ out_d2, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_n,
-                                                      HierArgs ha) {
+                                                      HierArgs ha, WaveBlend wb) {
   // Consecutive workgroups go to different XCDs (8 of them, each with its own L2): hand the list out in runs of WV_RUN workgroups
   // per XCD, so that the targets of neighbouring cells -- which read the same 27 cells -- meet in one L2, while all XCDs still
   // advance through the list together (one contiguous eighth per XCD: the dense parts of the cloud end up on a few XCDs, 1.6 x slower).
@@ -1011,6 +1013,33 @@ __global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams g
     const size_t row = (size_t)tr.id * (size_t)k;
     out_idx[row + lane] = W.li;
     if (out_d2) out_d2[row + lane] = W.ld;
+  }
+  if (wb.attr) {
+    // the blend of pt_attr.hip's blend_one, one neighbour per lane: a single gather instruction per target, whose latency hides
+    // behind the other waves' ranking (as a kernel of its own the 1.6e9 gathers of 50 M targets at k = 32 take 50 ms)
+    double w = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
+    if (lane < k && W.li != PT_NOIDX_U && W.li < wb.n_attr) {
+      w = wb.mode == 1 ? 1.0 / (W.ld + 1e-12) : 1.0;
+      const Attr a = pt_gather_attr(wb.attr, W.li);
+      a0 = w * (double)(a.rgba & 0xFFu); a1 = w * (double)((a.rgba >> 8) & 0xFFu); a2 = w * (double)((a.rgba >> 16) & 0xFFu);
+      b0 = w * (double)a.nx; b1 = w * (double)a.ny; b2 = w * (double)a.nz;
+    }
+#pragma unroll 1
+    for (int o = 32; o > 0; o >>= 1) {
+      w += __shfl_xor(w, o); a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o);
+      b0 += __shfl_xor(b0, o); b1 += __shfl_xor(b1, o); b2 += __shfl_xor(b2, o);
+    }
+    if (lane == 0) {
+      if (w > 0.0) {
+        const double iw = 1.0 / w;
+        a0 *= iw; a1 *= iw; a2 *= iw; b0 *= iw; b1 *= iw; b2 *= iw;
+        const double len = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
+        if (len >= 1e-12) { b0 /= len; b1 /= len; b2 /= len; }
+      }
+      const size_t t3 = 3 * (size_t)tr.id;
+      if (wb.rgb_out) { wb.rgb_out[t3] = (float)a0; wb.rgb_out[t3 + 1] = (float)a1; wb.rgb_out[t3 + 2] = (float)a2; }
+      if (wb.nrm_out) { wb.nrm_out[t3] = (float)b0; wb.nrm_out[t3 + 1] = (float)b1; wb.nrm_out[t3 + 2] = (float)b2; }
+    }
   }
 #ifdef PT_VISITS
   __builtin_amdgcn_wave_barrier();
@@ -1780,17 +1809,18 @@ uint32_t pt_mark_tiles(uint32_t m) { return (m + CP_TILE - 1) / CP_TILE; }
 template <class Rec>
 void pt_launch_knn_wave(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const uint32_t* cell_node, const uint32_t* nodes, uint32_t node_thr,
                         const Rec* tgt, uint32_t count, int k, const double* bound2, uint32_t* out_idx, double* out_d2, const uint32_t* list,
-                        const uint32_t* list_n, hipStream_t s) {
+                        const uint32_t* list_n, hipStream_t s, const Attr* attr, uint32_t n_attr, int blend_mode, float* rgb_out, float* nrm_out) {
   if (!count) return;
+  const WaveBlend wb{attr, n_attr, blend_mode, rgb_out, nrm_out};
   const uint32_t nwg = (((count + 3u) / 4u + 8u * WV_RUN - 1u) / (8u * WV_RUN)) * 8u * WV_RUN;      // whole rounds of 8 XCDs x WV_RUN workgroups (the kernel's mapping)
   const HierArgs ha{cell_node, nodes, node_thr, nullptr, 0u};
-  if (nodes) hipLaunchKernelGGL((knn_wave_kernel<Rec, true>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, count, k, bound2, out_idx, out_d2, list, list_n, ha);
-  else hipLaunchKernelGGL((knn_wave_kernel<Rec, false>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, count, k, bound2, out_idx, out_d2, list, list_n, ha);
+  if (nodes) hipLaunchKernelGGL((knn_wave_kernel<Rec, true>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, count, k, bound2, out_idx, out_d2, list, list_n, ha, wb);
+  else hipLaunchKernelGGL((knn_wave_kernel<Rec, false>), dim3(nwg), dim3(WG), 0, s, gp, src, cell_start, tgt, count, k, bound2, out_idx, out_d2, list, list_n, ha, wb);
 }
 template void pt_launch_knn_wave<RecF>(const GridParams&, const RecF*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const RecF*, uint32_t, int, const double*,
-                                       uint32_t*, double*, const uint32_t*, const uint32_t*, hipStream_t);
+                                       uint32_t*, double*, const uint32_t*, const uint32_t*, hipStream_t, const Attr*, uint32_t, int, float*, float*);
 template void pt_launch_knn_wave<RecD>(const GridParams&, const RecD*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const RecD*, uint32_t, int, const double*,
-                                       uint32_t*, double*, const uint32_t*, const uint32_t*, hipStream_t);
+                                       uint32_t*, double*, const uint32_t*, const uint32_t*, hipStream_t, const Attr*, uint32_t, int, float*, float*);
 
 // tile kernel over all blocks; targets it cannot settle are appended to todo[*todo_n] (todo_n zeroed by the caller).
 // geometry 1 = the two-workgroups-per-CU geometry (regions of <= PT_TILE_CAP_SMALL_* records), 0 = large.  With `attr` the

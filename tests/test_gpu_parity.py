@@ -659,6 +659,32 @@ def test_fused_query_blend_matches_the_two_calls(pkg, oracle, k, mode, tile):
     assert np.abs(rgb.cpu().numpy() - rc).max() / 255 <= TOL and np.abs(nrm.cpu().numpy() - rn).max() <= TOL
 
 
+@pytest.mark.parametrize("k,mode,tile,thr,f64", [(8, 0, 0, 0, False), (20, 1, 0, 16, False), (32, 0, 1, 0, False), (8, 1, 1, 24, True)])
+def test_fused_query_blend_on_the_wave_kernel(pkg, oracle, k, mode, tile, thr, f64):
+    """Clouds whose targets go to the one-wave-per-target kernel (forced here; with and without refined cells; alone or behind the
+    tile kernel): the blend happens inside that launch, one gather per lane -- same neighbours as the plain query, blended
+    attributes within tolerance of the oracle, for every target."""
+    import torch
+    n, m, seed = 200000, 8000, 0xB7
+    dist = pkg.capi.DIST_CLUSTERED
+    xt = pkg.F64 if f64 else pkg.F32
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.set_param("tile", tile); p.set_param("wave_force", 1); p.set_param("refine_threshold", thr)
+        p.build_synth(n, seed, dist=dist, xyz_type=xt)
+        p.targets_synth(m, seed, dist=dist, xyz_type=xt)
+        assert (p.stats()["n_nodes"] > 0) == (thr > 0)
+        i0 = torch.empty((m, k), dtype=torch.int32, device="cuda"); d0 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        p.query_resident_dev(k, i0, d0)
+        i1 = torch.full((m, k), 7, dtype=torch.int32, device="cuda"); d1 = torch.zeros((m, k), dtype=torch.float64, device="cuda")
+        rgb = torch.full((m, 3), -1.0, dtype=torch.float32, device="cuda"); nrm = torch.full((m, 3), -9.0, dtype=torch.float32, device="cuda")
+        p.query_blend_resident_dev(k, mode, i1, d1, rgb, nrm)
+        torch.cuda.synchronize()
+        assert p.stats()["n_wave"] > 0
+        assert torch.equal(i0, i1) and torch.equal(d0, d1)
+    rc, rn = oracle.blend(i0.cpu().numpy().view(np.uint32), d0.cpu().numpy(), oracle.synth_rgb(seed, n), oracle.synth_nrm(seed, n), mode)
+    assert np.abs(rgb.cpu().numpy() - rc).max() / 255 <= TOL and np.abs(nrm.cpu().numpy() - rn).max() <= TOL
+
+
 def test_fused_query_blend_double_cloud_and_errors(pkg):
     """fp64 clouds behind the fused call: same neighbours as the two calls, blend within tolerance; inverse-d2 without a
     d2 buffer is refused."""
