@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams g
     // behind the other waves' ranking (as a kernel of its own the 1.6e9 gathers of 50 M targets at k = 32 take 50 ms)
     double w = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
     if (lane < k && W.li != PT_NOIDX_U && W.li < wb.n_attr) {
-      w = wb.mode == 1 ? 1.0 / (W.ld + 1e-12) : 1.0;
+      w = wb.mode == 1 ? __builtin_amdgcn_rcp(W.ld + 1e-12) : 1.0;      // (v_rcp_f64 / v_rsq_f64, as in the tile kernel's epilogue: no division expanded into FMAs in this kernel)
       const Attr a = pt_gather_attr(wb.attr, W.li);
       a0 = w * (double)(a.rgba & 0xFFu); a1 = w * (double)((a.rgba >> 8) & 0xFFu); a2 = w * (double)((a.rgba >> 16) & 0xFFu);
       b0 = w * (double)a.nx; b1 = w * (double)a.ny; b2 = w * (double)a.nz;
@@ -1031,10 +1031,10 @@ __global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams g
     }
     if (lane == 0) {
       if (w > 0.0) {
-        const double iw = 1.0 / w;
+        const double iw = __builtin_amdgcn_rcp(w);
         a0 *= iw; a1 *= iw; a2 *= iw; b0 *= iw; b1 *= iw; b2 *= iw;
-        const double len = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
-        if (len >= 1e-12) { b0 /= len; b1 /= len; b2 /= len; }
+        const double l2 = (b0 * b0 + b1 * b1) + b2 * b2;
+        if (l2 >= 1e-24) { const double il = __builtin_amdgcn_rsq(l2); b0 *= il; b1 *= il; b2 *= il; }
       }
       const size_t t3 = 3 * (size_t)tr.id;
       if (wb.rgb_out) { wb.rgb_out[t3] = (float)a0; wb.rgb_out[t3 + 1] = (float)a1; wb.rgb_out[t3 + 2] = (float)a2; }
