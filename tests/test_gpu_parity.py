@@ -1182,6 +1182,29 @@ def test_wave_kernel_is_exact(pkg, oracle, kind, k, f64, thr, rho, wmin):
         assert np.array_equal(np.where(keep, want[0], 0xFFFFFFFF), bi) and np.array_equal(np.where(keep, want[1], np.inf), bd)
 
 
+def test_config5_shape_sampled_against_oracle(pkg, oracle):
+    """BASELINE config 5's own parameters at a tenth of its size: 30 M clustered points with fp16 coordinates (a lattice: hundreds of
+    exact duplicates per node in the clumps), 1.5 M targets, k = 32 -- tile kernel, wave kernel and its descending variant; a
+    sample is exact against the CPU kd-tree (ties among duplicates resolved by index)."""
+    import torch
+    n, m, k, seed = 30_000_000, 1_500_000, 32, 0xC5
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.build_synth(n, seed, dist=pkg.capi.DIST_CLUSTERED, xyz_type=pkg.F16)
+        p.targets_synth(m, seed, dist=pkg.capi.DIST_CLUSTERED, xyz_type=pkg.F16)
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+        p.query_resident_dev(k, idx, d2)
+        torch.cuda.synchronize()
+        st = p.stats()
+        assert st["n_wave"] > 0 and st["n_nodes"] > 0, st        # (at this size the tile kernel takes part of the targets, the wave kernel the rest)
+        assert bool((d2[:, 1:] >= d2[:, :-1]).all())
+        sel = np.random.default_rng(4).choice(m, 3000, replace=False)
+        I = idx[torch.from_numpy(sel).cuda()].cpu().numpy().view(np.uint32); D = d2[torch.from_numpy(sel).cuda()].cpu().numpy()
+    src = oracle.synth_xyz(seed, 0, n, dist=1, n_total=n, m_total=m).astype(np.float16).astype(np.float32)
+    tgt = np.concatenate([oracle.synth_xyz(seed, 1, 1, i0=int(t), dist=1, n_total=n, m_total=m) for t in sel], axis=1).astype(np.float16).astype(np.float32)
+    wi, wd = oracle.KdTree(src).query(tgt, k)
+    assert np.array_equal(I, wi) and np.array_equal(D, wd)
+
+
 @pytest.mark.parametrize("kind,f64", [("uniform", False), ("blobs", False), ("sheet", True)])
 def test_three_level_sort_for_very_fine_grids(pkg, oracle, kind, f64):
     """More than 1024 macro blocks (64^3 cells each): the sort partitions by GROUPS of macro blocks first, then by macro block, then
