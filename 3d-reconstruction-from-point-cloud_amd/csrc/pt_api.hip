@@ -67,6 +67,7 @@ struct pt_ctx {
   DevBuf x_xyz;                // transient targets of pt_query_soa / _aos / _bounded_dev (resident targets stay untouched)
   bool t_has_gidx = false;
   // refinement of heavy cells (pt_refine.hip): sub-grids inside cells with more than refine_threshold points
+  double refine_cpp = 2.0;              // ... and, in cells per point ("refine_cells_per_point")
   int refine_macros = PT_MAXBINS;       // finest grid the occupancy-driven refinement of h may ask for, in macro blocks (measured on the clustered
                                         // generator: beyond 1024 the extra sort pass costs more than the shorter scans save)
   // rebuilds of the SAME resident cloud (pt_rebuild) start from the cell size the last build ended with instead of searching for it again
@@ -203,10 +204,11 @@ void choose_grid(pt_ctx* c, const double mn[3], const double mx[3], double force
     h = std::max(h, maxext / 60000.0);     // <= ~2^16 cells per axis
     if (force_h > 0) h = std::max(force_h, maxext / 60000.0);
   }
-  // the refinement of h (force_h > 0) never asks for more than refine_macros macro blocks, nor for more cells than ~1.1 per point:
-  // measured on the clustered generator with the wave kernel taking the dense cells, 100M points are searched fastest at 384^3 - 448^3
-  // cells (27.7 ms per step; 37.6 at the 640^3 the occupancy rule would go to), 1B points at the 640^3 the macro limit allows
-  const uint64_t cap = force_h > 0 ? std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)c->refine_macros, (uint64_t)((double)c->n * 1.1 / 262144.0))) : (uint64_t)PT_MAX_MACROS;
+  // the refinement of h (force_h > 0) never asks for more than refine_macros macro blocks, nor for more than refine_cpp (2) cells per
+  // point.  Measured with the wave kernel taking the dense cells: the clustered generator at 100M points is fastest at ~1 cell per
+  // point (448^3: 19.0 ms per step; 19.8 at 2, 20.5 at 4 cells per point), a 50M-point surface (sphere shell, K = 20) at 3 - 4
+  // (11.1 ms at 1.1, 9.5 at 2, 9.2 at 3 - 4); 1B clustered points want the 640^3 the macro limit allows
+  const uint64_t cap = force_h > 0 ? std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)c->refine_macros, (uint64_t)((double)c->n * c->refine_cpp / 262144.0))) : (uint64_t)PT_MAX_MACROS;
   auto lay = [&](double hh) -> uint64_t {                 // grid of cell side hh; returns its number of macro blocks
     const double inv_h = 1.0 / hh;
     uint64_t nmacro = 1;
@@ -787,6 +789,7 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!strcmp(name, "adaptive")) { c->adaptive = value != 0; return PT_OK; }
   if (!strcmp(name, "tile")) { c->tile = (int)value; return PT_OK; }
   if (!strcmp(name, "grid_hint")) { c->grid_hint = value != 0; if (!c->grid_hint) c->hint_h = 0.0; return PT_OK; }
+  if (!strcmp(name, "refine_cells_per_point")) { if (!(value > 0 && value <= 1e6)) return fail(c, PT_ERR_ARG, "refine_cells_per_point out of range"); c->refine_cpp = value; return PT_OK; }
   if (!strcmp(name, "refine_macros")) { if (!(value >= 1 && value <= PT_MAX_MACROS)) return fail(c, PT_ERR_ARG, "refine_macros out of range"); c->refine_macros = (int)value; return PT_OK; }
   if (!strcmp(name, "wave_force")) { c->wave_force = value != 0; return PT_OK; }
   if (!strcmp(name, "wave_min")) { if (!(value >= 0 && value <= 4e9)) return fail(c, PT_ERR_ARG, "wave_min out of range"); c->wave_min = (uint32_t)value; return PT_OK; }

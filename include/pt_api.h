@@ -114,7 +114,8 @@ int  pt_set_stream(pt_ctx*, void* hip_stream);
  * "wave_min" (on such clouds a target whose 27 nearest cells hold at least this many points is answered by a whole wave instead of
  * an 8-lane group; default 1 = every target of such a cloud, 0 = never; "wave_force" = 1 applies that split to every cloud -- a testing hook), "refine_macros"
  * (the finest grid the refinement of the cell size may ask for, in 64^3-cell macro blocks: default 1024, at most 8192 -- grids beyond
- * 1024 macro blocks, which a cloud of more than ~1e9 points gets anyway, cost the sort one more partition pass), "grid_hint" (1,
+ * 1024 macro blocks, which a cloud of more than ~1e9 points gets anyway, cost the sort one more partition pass),
+ * "refine_cells_per_point" (that refinement also stops at this many grid cells per point; default 2), "grid_hint" (1,
  * default: pt_rebuild of the same resident cloud starts from the cell size the previous build ended with -- checked against the
  * occupancy it finds -- instead of searching for it again; 0: every build searches from scratch). */
 int  pt_set_param(pt_ctx*, const char* name, double value);

@@ -11,10 +11,13 @@ ref = None
 for spec in sys.argv[2:]:
     parts = [int(v) for v in spec.split(":")]
     thr, wmin, macros = parts[0], parts[1], (parts[2] if len(parts) > 2 else 0)
+    cpp = parts[3] if len(parts) > 3 else 0
     with pkg.PointsTransfer(device=0, k_hint=k) as p:
         p.set_param("refine_threshold", thr); p.set_param("wave_min", wmin)
         if macros:
             p.set_param("refine_macros", macros)
+        if cpp:
+            p.set_param("refine_cells_per_point", cpp)
         p.build_synth(n, 0xC5, dist=pkg.capi.DIST_CLUSTERED, xyz_type=xt); p.targets_synth(m, 0xC5, dist=pkg.capi.DIST_CLUSTERED, xyz_type=xt)
         idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
         for it in range(2):
