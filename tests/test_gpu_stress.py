@@ -58,12 +58,21 @@ def test_random_configuration_matches_oracle(pkg, oracle, case):
     if f64:
         src = src.astype(np.float64) + (rng.random(src.shape) - 0.5) * 1e-9 * (kind != "lattice")
         tgt = tgt.astype(np.float64)
+    # routing knobs (drawn last, so that the clouds of earlier rounds' cases stay what they were): who goes to the one-wave-per-target
+    # kernel, how heavy a cell must be to get a sub-grid, how fine the refinement of the cell size may go
+    wforce = int(rng.random() < 0.4); wmin = int(rng.choice([1, 1, 2, 300])); thr = int(rng.choice([8192, 8192, 0, 4, 40]))
+    cpp = float(rng.choice([2.0, 2.0, 0.5, 16.0]))
     with pkg.PointsTransfer(device=0, **kw) as p:
-        p.set_param("tile", tile)
+        p.set_param("tile", tile); p.set_param("wave_force", wforce); p.set_param("wave_min", wmin); p.set_param("refine_threshold", thr)
+        p.set_param("refine_cells_per_point", cpp)
         p.build(src, xyz_type=pkg.F64 if f64 else None)
         gi, gd = p.query(tgt, k, xyz_type=pkg.F64 if f64 else None)
+        if case % 3 == 0:                                                  # a rebuild starts from the remembered cell size: same answer
+            p.rebuild()
+            gi2, gd2 = p.query(tgt, k, xyz_type=pkg.F64 if f64 else None)
+            assert np.array_equal(gi, gi2) and np.array_equal(gd, gd2), "case %d: rebuild changed the answer" % case
     wi, wd = oracle.KdTree(src).query(tgt, k) if n else (np.full((m, k), 0xFFFFFFFF, np.uint32), np.full((m, k), np.inf))
-    what = "case %d: %s n=%d m=%d k=%d rho=%g tile=%d f64=%d" % (case, kind, n, m, k, rho, tile, f64)
+    what = "case %d: %s n=%d m=%d k=%d rho=%g tile=%d f64=%d wave=%d/%d thr=%d cpp=%g" % (case, kind, n, m, k, rho, tile, f64, wforce, wmin, thr, cpp)
     assert np.array_equal(gi, wi), what + ": indices differ in %d rows" % int((gi != wi).any(axis=1).sum())
     assert np.array_equal(gd, wd), what + ": d2 differ"
 
