@@ -522,8 +522,10 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
   const bool hier = c->n_nodes > 0;
   // Clouds with strong density contrast: targets whose 27 nearest cells hold many points (wave_min or more) are listed by the group
   // kernel instead of being answered, and get ONE WAVE EACH afterwards (knn_wave_kernel); one read-back of the list length.
-  // (also what the tile kernel leaves over at k > 16, where that is up to 12 % of the targets: 100M / 10M uniform, k = 32: 24.4 -> 22.3 ms)
-  const bool wave = c->wave_min > 0 && (contrast || hier || c->st.n_refine > 0 || c->wave_force || (use_tile && k > 16)) && m && k <= 64;
+  // (also what the tile kernel leaves over: up to 12 % of the targets at k > 16 -- 100M / 10M uniform, k = 32: 24.4 -> 22.3 ms -- and 0.2 %
+  //  at C4, 23.6 -> 23.1 ms; the list's length is read back to size that launch, so callers that asked for enqueue-only calls keep the
+  //  group kernel at k <= 16)
+  const bool wave = c->wave_min > 0 && (contrast || hier || c->st.n_refine > 0 || c->wave_force || (use_tile && (k > 16 || c->sync))) && m && k <= 64;
   // buffers of the split: marks (one byte per target), the two ordered lists (m words together), per-tile offsets and scan scratch
   const uint32_t mtiles = pt_mark_tiles(m);
   uint8_t* heavy = nullptr;

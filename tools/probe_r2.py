@@ -7,6 +7,8 @@ pkg = g.load_package()
 n, m, k, seed = 1_000_000_000, 50_000_000, 8, 0xC4
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 with pkg.PointsTransfer(device=0, k_hint=k) as p:
+    if len(sys.argv) > 2 and sys.argv[2] == "wave":
+        p.set_param("wave_force", 1)                # tile-kernel leftovers on the wave kernel
     p.build_synth(n, seed); p.targets_synth(m, seed)
     idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
     rgb = torch.empty((m, 3), dtype=torch.float32, device="cuda"); nrm = torch.empty((m, 3), dtype=torch.float32, device="cuda")
