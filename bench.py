@@ -200,9 +200,31 @@ def main():
         pt.targets_synth(m_total, seed, **gen)
     native = world > 1 and args.exchange == "native" and args.backend == "nccl"
     if native:        # the library's own RCCL communicator: rank 0 creates the id, torch.distributed only carries its 128 bytes
-        uid = [pt.comm_unique_id() if rank == 0 else None]
+        # Every rank must end up on the same protocol: if the communicator does not come up on ANY rank (librccl not loadable, an RCCL
+        # error), all of them fall back to the torch.distributed exchange -- said on stderr and in the JSON line's config.exchange.
+        ok = 1
+        try:
+            uid = [pt.comm_unique_id() if rank == 0 else None]
+        except Exception as e:                      # noqa: BLE001 -- whatever it is, the other ranks must not be left waiting
+            uid, ok = [None], 0
+            print("bench.py: rank %d: pt_comm_unique_id failed (%s)" % (rank, e), file=sys.stderr)
         dist.broadcast_object_list(uid, src=0, device=dev)
-        pt.comm_init(world, rank, uid[0])
+        if uid[0] is None:
+            ok = 0
+        else:
+            try:
+                pt.comm_init(world, rank, uid[0])
+            except Exception as e:                  # noqa: BLE001
+                ok = 0
+                print("bench.py: rank %d: pt_comm_init failed (%s)" % (rank, e), file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if ok:
+                pt.comm_destroy()
+            native = False
+            if rank == 0:
+                print("bench.py: native RCCL exchange unavailable on at least one rank: falling back to --exchange torch", file=sys.stderr)
     n_loc, m_loc = pt.num_source, pt.num_targets
     idx = torch.empty((m_loc, k), dtype=torch.int32, device=dev)
     d2 = torch.empty((m_loc, k), dtype=torch.float64, device=dev)
