@@ -22,6 +22,8 @@
 #include "../../include/pt_api.h"
 #include "pt_internal.h"
 
+#include <hip/hip_fp16.h>
+
 namespace {
 
 struct DevBuf {
@@ -49,6 +51,9 @@ struct pt_ctx {
   int src_type = -1;           // PT_F32 / PT_F64
   uint64_t n = 0, n_total = 0; // resident points; size of the attribute table
   DevBuf in_xyz, in_gidx, attr, rec, rec_tmp, cell_start;
+  bool in_half = false;          // fp16 clouds: in_xyz holds the coordinates as fp16 (src_type says PT_F32: that is what they are sorted into)
+  DevBuf xyz32;                  // ... and their fp32 image, made on demand for the few consumers of planar fp32 coordinates (PCA table, bake)
+  bool xyz32_valid = false;
   DevBuf rec32;                // fp64 clouds: fp32 shadow of the sorted records (id = sorted position), the tile kernel's LDS image
   bool rec32_valid = false;
   float e_src = 0.f;           // fp64 clouds: largest rounding error of a source coordinate stored as fp32
@@ -251,7 +256,11 @@ int run_source_sort(pt_ctx* c, uint64_t* bbox6_verify) {
 // bounding box of the resident cloud: every point (sample_stride = 1) or every sample_stride-th one
 int source_bbox(pt_ctx* c, uint32_t sample_stride, double (&mn)[3], double (&mx)[3]) {
   pt_launch_bbox_init((uint64_t*)c->bbox6.p, c->stream);
-  if (c->src_type == PT_F32) {
+  if (c->in_half) {
+    const __half* x = (const __half*)c->in_xyz.p;
+    if (sample_stride > 1) pt_launch_bbox_sample<__half>(x, x + c->n, x + 2 * c->n, (uint32_t)c->n, sample_stride, (uint64_t*)c->bbox6.p, c->stream);
+    else pt_launch_bbox<__half>(x, x + c->n, x + 2 * c->n, (uint32_t)c->n, (uint64_t*)c->bbox6.p, c->stream);
+  } else if (c->src_type == PT_F32) {
     const float* x = (const float*)c->in_xyz.p;
     if (sample_stride > 1) pt_launch_bbox_sample<float>(x, x + c->n, x + 2 * c->n, (uint32_t)c->n, sample_stride, (uint64_t*)c->bbox6.p, c->stream);
     else pt_launch_bbox<float>(x, x + c->n, x + 2 * c->n, (uint32_t)c->n, (uint64_t*)c->bbox6.p, c->stream);
@@ -265,6 +274,18 @@ int source_bbox(pt_ctx* c, uint32_t sample_stride, double (&mn)[3], double (&mx)
   for (int a = 0; a < 3; ++a) { mn[a] = pt_bbox_decode(c->h_bbox[a]); mx[a] = pt_bbox_decode(c->h_bbox[3 + a]); }
   for (int a = 0; a < 3; ++a)
     if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) return fail(c, PT_ERR_ARG, "source coordinates are not finite");
+  return PT_OK;
+}
+
+// the resident cloud's planar coordinates as fp32 (fp32 clouds: the input buffer itself; fp16-resident clouds: widened once per cloud)
+int source_xyz_f32(pt_ctx* c, const float** out) {
+  if (!c->in_half) { *out = (const float*)c->in_xyz.p; return PT_OK; }
+  if (!c->xyz32_valid) {
+    RES(c, c->xyz32, std::max<uint64_t>(c->n, 1) * 3 * sizeof(float));
+    pt_launch_half_to_float(c->in_xyz.p, (float*)c->xyz32.p, c->n * 3, c->stream);
+    c->xyz32_valid = true;
+  }
+  *out = (const float*)c->xyz32.p;
   return PT_OK;
 }
 
@@ -328,7 +349,7 @@ int rebuild(pt_ctx* c) {
     const bool verify = guessed && iter == 0;
     if (verify) pt_launch_bbox_init((uint64_t*)c->bbox6.p, c->stream);
     uint64_t* bv = verify ? (uint64_t*)c->bbox6.p : nullptr;
-    { const int r = c->src_type == PT_F32 ? run_source_sort<float, RecF>(c, bv) : run_source_sort<double, RecD>(c, bv); if (r != PT_OK) return r; }
+    { const int r = c->in_half ? run_source_sort<__half, RecF>(c, bv) : (c->src_type == PT_F32 ? run_source_sort<float, RecF>(c, bv) : run_source_sort<double, RecD>(c, bv)); if (r != PT_OK) return r; }
     if (verify) {
       HIPCHK(c, hipMemcpyAsync(c->h_bbox, c->bbox6.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -755,7 +776,7 @@ void pt_ctx_destroy(pt_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in_xyz, &c->in_gidx, &c->attr, &c->rec, &c->rec_tmp, &c->cell_start, &c->stb_mem, &c->t_xyz, &c->t_gidx, &c->trec,
                    &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr, &c->retry, &c->rec32, &c->up_rgb, &c->up_nrm, &c->x_bounds, &c->x_counts, &c->x_matrix, &c->x_off, &c->x_req, &c->x_row, &c->x_rreq,
-                   &c->x_rxyz, &c->x_rbound, &c->x_ans_i, &c->x_ans_d, &c->x_back_i, &c->x_back_d, &c->x_flags, &c->x_rows, &c->cell_node, &c->nodes, &c->heavy, &c->near_node};
+                   &c->x_rxyz, &c->x_rbound, &c->x_ans_i, &c->x_ans_d, &c->x_back_i, &c->x_back_d, &c->x_flags, &c->x_rows, &c->cell_node, &c->nodes, &c->heavy, &c->near_node, &c->xyz32};
   for (DevBuf* b : all) release(c, *b);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);
@@ -831,7 +852,7 @@ int pt_build_aos(pt_ctx* c, const pt_point* cloud, uint64_t n) {
   { int r = copy_in(c, c->aos_stage.p, cloud, n * sizeof(pt_point), 0); if (r) return r; }
   double* x = (double*)c->in_xyz.p;
   pt_launch_aos_split(c->aos_stage.p, (uint32_t)n, x, x + n, x + 2 * n, (Attr*)c->attr.p, c->stream);
-  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0;
+  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -839,14 +860,22 @@ int pt_build_soa_indexed(pt_ctx* c, const void* xyz, int xyz_type, const uint32_
   if (!c) return PT_ERR_ARG;
   { int r = check_n(c, n, "n"); if (r) return r; }
   HIPCHK(c, hipSetDevice(c->device));
-  { int r = upload_xyz(c, c->in_xyz, xyz, xyz_type, n, on_device); if (r) return r; }
+  const bool keep_half = xyz_type == PT_F16;            // fp16 clouds stay fp16 in the resident input: 6 bytes per point for pass 1 to read
+  if (keep_half) {
+    if (n && !xyz) return fail(c, PT_ERR_ARG, "xyz is null");
+    RES(c, c->in_xyz, std::max<uint64_t>(n, 1) * 3 * sizeof(__half));
+    { int r = copy_in(c, c->in_xyz.p, xyz, n * 3 * sizeof(__half), on_device); if (r) return r; }
+    xyz_type = PT_F32;
+  } else {
+    int r = upload_xyz(c, c->in_xyz, xyz, xyz_type, n, on_device); if (r) return r;
+  }
   if (gidx) {
     RES(c, c->in_gidx, std::max<uint64_t>(n, 1) * sizeof(uint32_t));
     { int r = copy_in(c, c->in_gidx.p, gidx, n * sizeof(uint32_t), on_device); if (r) return r; }
   }
   c->src_type = xyz_type; c->n = n; c->has_gidx = gidx != nullptr; c->built = false;
   if (!gidx) { c->n_total = n; c->has_attr = false; }
-  c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0;
+  c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -880,7 +909,7 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
   if (!c) return PT_ERR_ARG;
   if (dist != PT_DIST_UNIFORM && dist != PT_DIST_CLUSTERED) return fail(c, PT_ERR_ARG, "unknown distribution %d", dist);
   if (xyz_type != PT_F32 && xyz_type != PT_F64 && xyz_type != PT_F16) return fail(c, PT_ERR_ARG, "unknown xyz_type %d", xyz_type);
-  const int f16 = xyz_type == PT_F16;      // fp16 values, held widened as fp32 on the device
+  const int f16 = xyz_type == PT_F16;      // fp16 values: resident as fp16, sorted into fp32 records (widening is exact)
   if (f16) xyz_type = PT_F32;
   if (slab_axis > 2) return fail(c, PT_ERR_ARG, "slab_axis must be < 3");
   { int r = check_n(c, n_total, "n_total"); if (r) return r; }
@@ -896,13 +925,15 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
     RES(c, c->in_gidx, std::max<uint64_t>(n, 1) * sizeof(uint32_t));
     HIPCHK(c, hipMemsetAsync(c->counter.p, 0, 4, c->stream));
   }
-  RES(c, c->in_xyz, std::max<uint64_t>(n, 1) * 3 * tsize(xyz_type));
+  const bool keep_half = f16 != 0;
+  RES(c, c->in_xyz, std::max<uint64_t>(n, 1) * 3 * (keep_half ? sizeof(__half) : tsize(xyz_type)));
   uint32_t* g = slab ? (uint32_t*)c->in_gidx.p : nullptr;
-  if (xyz_type == PT_F32) { float* x = (float*)c->in_xyz.p; pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream); }
+  if (keep_half) { __half* x = (__half*)c->in_xyz.p; pt_launch_synth_xyz<__half>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, 1, dist, n_total, 0, c->stream); }
+  else if (xyz_type == PT_F32) { float* x = (float*)c->in_xyz.p; pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream); }
   else { double* x = (double*)c->in_xyz.p; pt_launch_synth_xyz<double>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream); }
   RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
   pt_launch_synth_attr(seed, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
-  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0;
+  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -1136,7 +1167,8 @@ int pt_pca_normals_dev(pt_ctx* c, const uint32_t* idx_dev, uint64_t m, int k, fl
   if (c->src_type == PT_F32) {
     // one 32-byte gather per neighbour instead of four 4..16-byte ones: the table depends on the cloud only, so it is
     // built on the first call after an upload and reused by every later one (rebuilds of the grid do not touch it)
-    const float* x = (const float*)c->in_xyz.p;
+    const float* x = nullptr;
+    if (!c->posattr_valid) { int r = source_xyz_f32(c, &x); if (r) return r; }
     if (!c->posattr_valid) {
       RES(c, c->posattr, std::max<uint64_t>(c->n, 1) * 32);
       pt_launch_pack_posattr(x, x + c->n, x + 2 * c->n, at, (uint32_t)c->n, c->posattr.p, c->stream);
@@ -1277,7 +1309,7 @@ int pt_upload_end(pt_ctx* c) {
   if (c->up_attr) pt_launch_pack_attr((const uint8_t*)c->up_rgb.p, (const float*)c->up_nrm.p, (uint32_t)n, (Attr*)c->attr.p, c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));                                // the caller's buffers are free again
   c->src_type = c->up_type; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = c->up_attr != 0; c->built = false;
-  c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0;
+  c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
   c->up_type = -1;
   release(c, c->up_rgb); release(c, c->up_nrm);
   return rebuild(c);
@@ -1303,8 +1335,10 @@ int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64
   hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
   const int sync_save = c->sync;
   DevBuf keep_in = c->in_xyz;                       // the context's own input buffer: put back at the end (the chunks live in `stage`)
+  const bool keep_half = c->in_half;
   auto cleanup = [&]() {
     c->in_xyz = keep_in;
+    c->in_half = keep_half; c->xyz32_valid = false;
     c->sync = sync_save;
     DevBuf* all[] = {&best_i[0], &best_i[1], &best_d[0], &best_d[1], &ci, &cd, &stage[0], &stage[1]};
     for (DevBuf* b : all) release(c, *b);
@@ -1342,7 +1376,7 @@ int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64
       HIPCHK(c, hipStreamWaitEvent(c->stream, copied[b], 0));
       c->in_xyz = stage[b];
       c->src_type = xyz_type; c->n = cnt; c->n_total = cnt; c->has_gidx = false; c->has_attr = false; c->built = false;
-      c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0;
+      c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
       { int r = rebuild(c); if (r) return r; }
       HIPCHK(c, hipEventRecord(consumed[b], c->stream));               // the build no longer reads stage[b] (records hold the coordinates)
       { int r = run_query(c, c->t_xyz.p, c->tgt_type, m, k, nullptr, (uint32_t*)ci.p, (double*)cd.p); if (r) return r; }
@@ -1698,7 +1732,8 @@ int pt_bake_texture(pt_ctx* c, const pt_point* mesh_vertices, uint64_t nv, const
     { int r = copy_in(c, dn.p, nbr_idx, nv * (size_t)k * 4, 0); if (r) return r; }
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     if (c->src_type == PT_F32) {
-      const float* x = (const float*)c->in_xyz.p;
+      const float* x = nullptr;
+      { int r = source_xyz_f32(c, &x); if (r) return r; }
       pt_launch_bake_faces<float>(x, x + c->n, x + 2 * c->n, (const Attr*)c->attr.p, (uint32_t)c->n, dv.p, (uint32_t)nv, (const int32_t*)df.p, (uint32_t)nf,
                                   (const uint32_t*)dn.p, k, resolution, (unsigned long long*)keys.p, c->stream);
     } else {

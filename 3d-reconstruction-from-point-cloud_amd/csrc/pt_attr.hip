@@ -353,6 +353,8 @@ void pt_launch_synth_xyz(uint64_t seed, uint64_t stream, uint32_t n_total, int a
 }
 template void pt_launch_synth_xyz<float>(uint64_t, uint64_t, uint32_t, int, double, double, float*, float*, float*, uint32_t*, uint32_t*, uint32_t,
                                          int, int, uint64_t, uint64_t, hipStream_t);
+template void pt_launch_synth_xyz<__half>(uint64_t, uint64_t, uint32_t, int, double, double, __half*, __half*, __half*, uint32_t*, uint32_t*, uint32_t,
+                                          int, int, uint64_t, uint64_t, hipStream_t);
 template void pt_launch_synth_xyz<double>(uint64_t, uint64_t, uint32_t, int, double, double, double*, double*, double*, uint32_t*, uint32_t*,
                                           uint32_t, int, int, uint64_t, uint64_t, hipStream_t);
 

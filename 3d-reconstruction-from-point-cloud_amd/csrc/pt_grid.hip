@@ -17,6 +17,8 @@
 // All of this is HBM-bound byte shuffling: no MFMA, wave64 everywhere, 256-thread workgroups.
 #include "pt_internal.h"
 
+#include <hip/hip_fp16.h>
+
 #include <algorithm>
 #include <cstring>
 
@@ -27,6 +29,10 @@ constexpr int WG = 256;
 template <class T> struct RecOf;
 template <> struct RecOf<float> { using type = RecF; };
 template <> struct RecOf<double> { using type = RecD; };
+template <> struct RecOf<__half> { using type = RecF; };          // fp16 clouds stay fp16 in the resident input (6 B / point read by pass 1 and
+                                                                  // its histogram instead of 12); the records they are sorted into are fp32 (exact)
+template <class T> __device__ inline T pt_widen(T v) { return v; }
+__device__ inline float pt_widen(__half v) { return __half2float(v); }
 
 template <class T>
 struct PlanarLoader {
@@ -35,7 +41,7 @@ struct PlanarLoader {
   const uint32_t* gidx;
   __device__ Rec load(uint32_t i) const {
     Rec r;
-    r.x = x[i]; r.y = y[i]; r.z = z[i];
+    r.x = pt_widen(x[i]); r.y = pt_widen(y[i]); r.z = pt_widen(z[i]);
     r.id = gidx ? gidx[i] : i;
     return r;
   }
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(WG) void bbox_kernel(const T* __restrict__ x, const
                                                   uint64_t* out6) {
   double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) {
-    const double v[3] = {(double)x[i], (double)y[i], (double)z[i]};
+    const double v[3] = {(double)pt_widen(x[i]), (double)pt_widen(y[i]), (double)pt_widen(z[i])};
 #pragma unroll
     for (int a = 0; a < 3; ++a) { mn[a] = (v[a] != v[a]) ? -INFINITY : fmin(mn[a], v[a]); mx[a] = fmax(mx[a], v[a]); }   // NaN: fmin / fmax would drop it
   }
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(WG) void bbox_sample_kernel(const T* __restrict__ x
   double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   const uint64_t span = (uint64_t)stride * WG;
   for (uint64_t i = (uint64_t)blockIdx.x * span + threadIdx.x; i < n; i += (uint64_t)gridDim.x * span) {
-    const double v[3] = {(double)x[i], (double)y[i], (double)z[i]};
+    const double v[3] = {(double)pt_widen(x[i]), (double)pt_widen(y[i]), (double)pt_widen(z[i])};
 #pragma unroll
     for (int a = 0; a < 3; ++a) { mn[a] = (v[a] != v[a]) ? -INFINITY : fmin(mn[a], v[a]); mx[a] = fmax(mx[a], v[a]); }   // NaN: fmin / fmax would drop it
   }
@@ -647,6 +653,8 @@ void pt_launch_bbox_sample(const T* x, const T* y, const T* z, uint32_t n, uint3
   const uint32_t runs = (uint32_t)((n + span - 1) / span);
   hipLaunchKernelGGL(bbox_sample_kernel<T>, dim3(std::min<uint32_t>(runs, 256u)), dim3(WG), 0, s, x, y, z, n, stride, out6);
 }
+template void pt_launch_bbox_sample<__half>(const __half*, const __half*, const __half*, uint32_t, uint32_t, uint64_t*, hipStream_t);
+template void pt_launch_bbox<__half>(const __half*, const __half*, const __half*, uint32_t, uint64_t*, hipStream_t);
 template void pt_launch_bbox_sample<float>(const float*, const float*, const float*, uint32_t, uint32_t, uint64_t*, hipStream_t);
 template void pt_launch_bbox_sample<double>(const double*, const double*, const double*, uint32_t, uint32_t, uint64_t*, hipStream_t);
 template void pt_launch_bbox<float>(const float*, const float*, const float*, uint32_t, uint64_t*, hipStream_t);
@@ -798,6 +806,8 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
   return done(do_finalize ? out_final : tmp);
 }
 template const RecF* pt_launch_grid_sort<float, RecF>(const GridParams&, const float*, const float*, const float*, const uint32_t*, uint32_t, RecF*,
+                                                      RecF*, uint32_t*, const SortTables&, bool, hipStream_t, uint64_t*);
+template const RecF* pt_launch_grid_sort<__half, RecF>(const GridParams&, const __half*, const __half*, const __half*, const uint32_t*, uint32_t, RecF*,
                                                       RecF*, uint32_t*, const SortTables&, bool, hipStream_t, uint64_t*);
 template const RecD* pt_launch_grid_sort<double, RecD>(const GridParams&, const double*, const double*, const double*, const uint32_t*, uint32_t,
                                                        RecD*, RecD*, uint32_t*, const SortTables&, bool, hipStream_t, uint64_t*);

@@ -127,7 +127,9 @@ int  pt_synchronize(pt_ctx*);
 /* AoS reference records on the host (80-B stride); coordinates are kept as double on the GPU. */
 int  pt_build_aos(pt_ctx*, const pt_point* cloud, uint64_t n);
 /* Planar xyz of `xyz_type` (+ optional interleaved rgb u8[n][3] and normals f32[n][3]); host or
- * device memory according to on_device. */
+ * device memory according to on_device. PT_F16 clouds stay fp16 in the resident input (6 bytes per
+ * point) and are widened -- exactly -- as the build reads them; answers are those of the fp32 cloud
+ * holding the same values. */
 int  pt_build_soa(pt_ctx*, const void* xyz, int xyz_type, const uint8_t* rgb, const float* nrm,
                   uint64_t n, int on_device);
 /* Same, for one spatial slab of a larger cloud: gidx[i] is the point's index in the whole cloud

@@ -346,16 +346,21 @@ def test_pca_matches_golden(pt, oracle, golden, golden_cases):
     assert ok.any() and np.abs(got[ok] - golden["c1_k16_pca_nrm"][ok]).max() <= 1e-4
 
 
-def test_pca_normals(pt, oracle):
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_pca_normals(pt, oracle, dtype):
+    """fp16 clouds stay fp16 in the resident input; the PCA table is packed from their fp32 image (made on demand)."""
     rng = np.random.default_rng(5)
     n = 50000
     src = rng.random((3, n)).astype(np.float32)
     src[2] = (0.3 + 0.1 * src[0] + 0.05 * np.sin(6 * src[1]) + 1e-3 * rng.standard_normal(n)).astype(np.float32)   # a noisy surface
+    src = src.astype(dtype)
     nrm = np.tile(np.array([0, 0, 1], np.float32), (n, 1))
     tgt = src[:, :3000].copy()
     pt.build(src, None, nrm)
     idx, d2 = pt.query(tgt, 16)
+    _check_exact((idx, d2), oracle.knn_bruteforce(src.astype(np.float64), tgt.astype(np.float64), 16), "surface cloud")
     got = pt.pca_normals(idx)
+    src = src.astype(np.float32)
     want, plan = oracle.pca_normals(idx, src, nrm)
     ok = plan < 0.1                                  # well-conditioned neighbourhoods
     assert ok.mean() > 0.9
@@ -800,10 +805,15 @@ def test_double_cloud_with_coordinates_beyond_float_range(pkg, oracle):
 
 # ---- texture bake: atlas bytes against the oracle ----------------------------------------------------
 @pytest.mark.parametrize("seed,n,grid,k,R,degenerate,f64", [(1, 6000, 6, 20, 512, False, True), (2, 20000, 9, 20, 700, False, False),
-                                                           (5, 3000, 3, 8, 128, True, True), (7, 1500, 2, 32, 257, True, False)])
+                                                           (5, 3000, 3, 8, 128, True, True), (7, 1500, 2, 32, 257, True, False),
+                                                           (3, 5000, 5, 20, 300, False, "f16")])
 def test_texture_bake_matches_oracle(pkg, oracle, seed, n, grid, k, R, degenerate, f64):
     from _bake_cases import make_case, point_records
     src, rgb, verts, uv, vrgb, faces = make_case(seed, n=n, grid=grid, degenerate=degenerate)
+    half = f64 == "f16"                     # fp16-resident cloud: the bake reads its fp32 image
+    f64 = f64 is True
+    if half:
+        src = src.astype(np.float16).astype(np.float64)
     if not f64:
         src = src.astype(np.float32).astype(np.float64); verts = verts.astype(np.float32).astype(np.float64)
     if degenerate:
@@ -815,7 +825,7 @@ def test_texture_bake_matches_oracle(pkg, oracle, seed, n, grid, k, R, degenerat
             vrec = point_records(pkg.POINT_DTYPE, verts, vrgb, uv)
             idx, d2 = p.query_aos(vrec, k)
         else:
-            p.build(src.astype(np.float32), rgb, np.zeros((n, 3), np.float32))
+            p.build(src.astype(np.float16 if half else np.float32), rgb, np.zeros((n, 3), np.float32))
             vrec = point_records(pkg.POINT_DTYPE, verts, vrgb, uv)
             idx, d2 = p.query(verts.astype(np.float32), k)
         wi, wd = oracle.knn_bruteforce(src, verts, k)
