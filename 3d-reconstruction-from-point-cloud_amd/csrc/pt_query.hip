@@ -659,11 +659,15 @@ struct WaveScan {
   double lim_d, bnd_d;         // acceptance limit = min(entry of rank k-1, caller's bound): wave-uniform
   uint32_t lim_i;
   int k, lane;
+  // candidates set aside (k >= PEND_MIN_K): this wave's 64 slots in LDS and how many are taken (wave-uniform); see offer()
+  double* pend_d;
+  uint32_t* pend_i;
+  uint32_t npend;
 #ifdef PT_VISITS
   uint32_t nv = 0, nn = 0;     // instrumented build: steps of 64 records, nodes entered
 #endif
 
-  __device__ void reset() { ld = INFINITY; li = PT_NOIDX_U; lim_d = bnd_d; lim_i = PT_NOIDX_U; }
+  __device__ void reset() { ld = INFINITY; li = PT_NOIDX_U; lim_d = bnd_d; lim_i = PT_NOIDX_U; npend = 0; }
   __device__ void refresh() {
     const double kd = readlane_f64(ld, k - 1);
     const uint32_t ki = readlane_u32(li, k - 1);
@@ -689,38 +693,76 @@ struct WaveScan {
   // slots across the lanes (bitonic, 21 exchange stages), take the 64 smallest of list and candidates (list[i] against candidate
   // [63 - i]) and sort that bitonic sequence (6 stages) -- ~400 instructions whatever the number of candidates, against ~60 for
   // each one-by-one insertion.  Keys are distinct (ids) except the empty slots (+inf, NOIDX), whose order does not matter.
-  // (raw ds_bpermute on a byte address: HIP's __shfl_xor spends four more instructions per call on range checks)
-  __device__ void exchange(double& xd, uint32_t& xi, int j, bool keep_min) const {
-    const int a = (lane ^ j) << 2;
-    const int plo = __builtin_amdgcn_ds_bpermute(a, __double2loint(xd)), phi = __builtin_amdgcn_ds_bpermute(a, __double2hiint(xd));
-    const uint32_t pi = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)xi);
-    const double pd = __hiloint2double(phi, plo);
-    // partner < mine, or mine < partner: the keys differ unless both slots are empty (then nothing moves)
-    const bool plt = key_lt_flat(pd, pi, xd, xi), take = keep_min ? plt : (!plt && !(pd == xd && pi == xi));
-    if (take) { xd = pd; xi = pi; }
+  // The exchanges never touch the LDS: partner lane ^ 1, ^ 2 by DPP quad permutes, ^ 4 by two bank-masked row shifts, ^ 8 by a row
+  // rotation, ^ 16 and ^ 32 by gfx950's v_permlane16_swap / v_permlane32_swap (both copies of the value go in; each lane picks the
+  // one that holds its partner's).  With ds_bpermute every one of the 27 stages was an LDS round trip.
+  template <int J>
+  __device__ __forceinline__ uint32_t xor_lane(uint32_t x) const {
+    if constexpr (J == 1) return dpp_u32<0xB1>(x);                                       // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return dpp_u32<0x4E>(x);                                  // quad_perm [2,3,0,1]
+    else if constexpr (J == 4) {
+      const int t = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x104, 0xF, 0x5, false);  // row_shl:4 into lanes 0-3, 8-11 of a row
+      return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xF, 0xA, false);    // row_shr:4 into lanes 4-7, 12-15
+    } else if constexpr (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x128, 0xF, 0xF, false);   // row_ror:8
+    else if constexpr (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); return (lane & 16) ? r[0] : r[1]; }
+    else { const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); return (lane & 32) ? r[0] : r[1]; }
   }
-  __device__ void merge64(double cd, uint32_t ci) {
-#pragma unroll 1
-    for (int k2 = 2; k2 <= 64; k2 <<= 1) {                  // (rolled: one exchange body instead of 27, and no table of lane masks in SGPRs)
-#pragma unroll 1
-      for (int j = k2 >> 1; j > 0; j >>= 1) exchange(cd, ci, j, ((lane & j) == 0) == ((lane & k2) == 0));
-    }
-    const double rd = __shfl(cd, 63 - lane);
-    const uint32_t ri = (uint32_t)__shfl((int)ci, 63 - lane);
-    if (key_lt_flat(rd, ri, ld, li)) { ld = rd; li = ri; }
-#pragma unroll 1
-    for (int j = 32; j > 0; j >>= 1) exchange(ld, li, j, (lane & j) == 0);
+  template <int J>
+  __device__ __forceinline__ void exchange(double& xd, uint32_t& xi, bool keep_min) const {
+    const uint32_t plo = xor_lane<J>((uint32_t)__double2loint(xd)), phi = xor_lane<J>((uint32_t)__double2hiint(xd)), pi = xor_lane<J>(xi);
+    const double pd = __hiloint2double((int)phi, (int)plo);
+    // keep_min: take the partner's if it is smaller; else take it unless it is smaller (equal keys -- two empty slots -- swap to no effect)
+    if (key_lt_flat(pd, pi, xd, xi) == keep_min) { xd = pd; xi = pi; }
   }
-  static constexpr int MERGE_MIN = 16;
-  // one candidate per lane (d = +inf for lanes without one)
-  __device__ void offer(double d, uint32_t id) {
-    const bool pass = key_lt_flat(d, id, lim_d, lim_i) && !(d > bnd_d);
-    unsigned long long mask = __ballot(pass);
-    if (__popcll(mask) >= MERGE_MIN) {                      // wave-uniform
-      merge64(pass ? d : INFINITY, pass ? id : PT_NOIDX_U);
-      refresh();
-      return;
-    }
+  // the exchange stages of one bitonic block size k2 (partners ^ k2/2 ... ^ 1); k2 is a constant wherever this is used
+  __device__ __forceinline__ void stages(double& xd, uint32_t& xi, int k2, int l) const {
+    const bool up = (l & k2) == 0;
+    if (k2 > 32) exchange<32>(xd, xi, ((l & 32) == 0) == up);          // wave-uniform tests
+    if (k2 > 16) exchange<16>(xd, xi, ((l & 16) == 0) == up);
+    if (k2 > 8) exchange<8>(xd, xi, ((l & 8) == 0) == up);
+    if (k2 > 4) exchange<4>(xd, xi, ((l & 4) == 0) == up);
+    if (k2 > 2) exchange<2>(xd, xi, ((l & 2) == 0) == up);
+    exchange<1>(xd, xi, ((l & 1) == 0) == up);
+  }
+  // The merge itself is ONE function in the code object, called (values in, values out: nothing of the scan's state goes through
+  // memory) from wherever a scan offers candidates: inlined at every such place, its 27 stages pushed the kernel out of the
+  // instruction cache and the registers -- 480 ms at C5's shape against 325 ms called, 365 ms with the rolled ds_bpermute form.
+  struct KeyDI { double d; uint32_t i; };
+  __device__ __attribute__((noinline)) static KeyDI merge_core(double ld_, uint32_t li_, double cd, uint32_t ci) {
+    WaveScan t;
+    t.lane = (int)__lane_id();
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) t.stages(cd, ci, k2, t.lane);      // candidates sorted across the lanes
+    const double rd = __shfl(cd, 63 - t.lane);
+    const uint32_t ri = (uint32_t)__shfl((int)ci, 63 - t.lane);
+    if (key_lt_flat(rd, ri, ld_, li_)) { ld_ = rd; li_ = ri; }              // the 64 smallest of list and candidates: a bitonic sequence
+    t.stages(ld_, li_, 64, t.lane);
+    return KeyDI{ld_, li_};
+  }
+  __device__ __forceinline__ void merge64(double cd, uint32_t ci) {
+    const KeyDI r = merge_core(ld, li, cd, ci);
+    ld = r.d; li = r.i;
+  }
+#ifndef PT_MERGE_MIN
+#define PT_MERGE_MIN 16
+#endif
+#ifndef PT_PEND_FLUSH
+#define PT_PEND_FLUSH 48
+#endif
+#ifndef PT_PEND_MIN_K
+#define PT_PEND_MIN_K 12
+#endif
+  static constexpr int MERGE_MIN = PT_MERGE_MIN;
+  // Steps with few candidates -- the long tail of a dense cell: k ln(n / k) of them, one or two per step -- do not insert them one by
+  // one (~35 instructions each, most of this kernel's instructions at k = 32): the candidates are set aside in LDS (a ballot, a
+  // prefix count, one exec-masked write) and the list takes PEND_FLUSH of them in ONE sort-merge.  The limit stays where the last
+  // merge left it meanwhile -- an upper bound of the final k-th distance like any other, so nothing is lost; ~35 % more records
+  // pass it, and the whole costs ~40 % fewer instructions at k = 32, a third fewer at k = 20, none at k = 8 (simulated on random
+  // orders; hence PEND_MIN_K).  Whoever DECIDES by the limit (which cells to read next, whether the ring was the last) calls
+  // flush() first.
+  static constexpr int PEND_FLUSH = PT_PEND_FLUSH, PEND_MIN_K = PT_PEND_MIN_K;
+  static_assert(PEND_FLUSH + MERGE_MIN - 2 < 64, "the slots of one wave");
+  __device__ __forceinline__ void insert_each(double d, uint32_t id, unsigned long long mask) {
     while (mask) {                                          // wave-uniform
       const int j = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
@@ -729,6 +771,37 @@ struct WaveScan {
       // (no second look at the limit: a candidate that no longer beats it lands beyond rank k - 1, where it is harmless)
       if (insert(xd, xi) < k) refresh();
     }
+  }
+  __device__ __forceinline__ void flush() {
+    if (!npend) return;                                     // wave-uniform
+    const uint32_t n = npend;                               // < 64: PEND_FLUSH - 1 + MERGE_MIN - 1 at most
+    npend = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the slots were written by this wave's own lanes: LDS keeps a wave's order
+    __builtin_amdgcn_wave_barrier();
+    double d = INFINITY;
+    uint32_t id = PT_NOIDX_U;
+    if ((uint32_t)lane < n) { d = pend_d[lane]; id = pend_i[lane]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // ... and the next round's writes stay behind these reads
+    __builtin_amdgcn_wave_barrier();
+    if (n >= (uint32_t)MERGE_MIN) { merge64(d, id); refresh(); }
+    else insert_each(d, id, (1ull << n) - 1ull);
+  }
+  // one candidate per lane (d = +inf for lanes without one)
+  __device__ __forceinline__ void offer(double d, uint32_t id) {
+    const bool pass = key_lt_flat(d, id, lim_d, lim_i) && !(d > bnd_d);
+    const unsigned long long mask = __ballot(pass);
+    if (!mask) return;                                      // wave-uniform (as every branch below)
+    const uint32_t c = (uint32_t)__popcll(mask);
+    if (c >= (uint32_t)MERGE_MIN) {
+      merge64(pass ? d : INFINITY, pass ? id : PT_NOIDX_U);
+      refresh();
+      return;
+    }
+    if (k < PEND_MIN_K) { insert_each(d, id, mask); return; }
+    const uint32_t slot = npend + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    if (pass) { pend_d[slot] = d; pend_i[slot] = id; }
+    npend += c;
+    if (npend >= (uint32_t)PEND_FLUSH) flush();
   }
   // WPF steps of loads are in flight while a step is ranked: with one, every step of 64 records cost a full memory latency (60 us
   // per target at 25 - 35 steps, measured: the steps' arithmetic is ~0.15 us)
@@ -821,6 +894,7 @@ struct WaveScan {
 #ifdef PT_VISITS
     ++nn;
 #endif
+    flush();                                                // the rows are chosen by the limit
     {
       const double* hd = reinterpret_cast<const double*>(N);
       const double ox = hd[0], oy = hd[1], oz = hd[2], inv = hd[3], w = hd[4];
@@ -896,8 +970,11 @@ __global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams g
 #ifdef PT_VISITS
   const unsigned long long pt_t0 = wall_clock64();
 #endif
+  __shared__ double pend_d[WG / 64][64];
+  __shared__ uint32_t pend_i[WG / 64][64];
   WaveScan<Rec> W;
   W.src = src; W.nodes = ha.nodes; W.k = k; W.lane = lane;
+  W.pend_d = pend_d[threadIdx.x >> 6]; W.pend_i = pend_i[threadIdx.x >> 6];
   W.q[0] = (double)tr.x; W.q[1] = (double)tr.y; W.q[2] = (double)tr.z;
   W.h2 = gp.h * gp.h;
   int c[3];
@@ -958,6 +1035,7 @@ __global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams g
       if (n0) W.template node<0>(n0);
       else W.range(s0, e0);
       if (lane == 0) { S = E = 0; nid = 0; }
+      W.flush();                                            // the limit the own cell leaves decides which of the other 26 are read
     }
     const bool on = E > S && !(g2 * W.h2 > W.lim_d);
     W.stream(S, on && !nid ? E - S : 0u);
@@ -972,6 +1050,7 @@ __global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams g
     }
     if (st >= 0 && ++st < nst) continue;
     // ring rr is complete: every unscanned point lies beyond one of the box faces that still has cells behind it
+    W.flush();
     bool covered = true;
     double dout = INFINITY;
 #pragma unroll
@@ -1009,6 +1088,7 @@ __global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams g
     st = 0;
     { const int side = 2 * rr + 1; nst = (side * side * side - (side - 2) * (side - 2) * (side - 2) + 63) / 64; }
   }
+  W.flush();                                                // (the block sweep ends with candidates set aside)
   if (lane < k) {
     const size_t row = (size_t)tr.id * (size_t)k;
     out_idx[row + lane] = W.li;
