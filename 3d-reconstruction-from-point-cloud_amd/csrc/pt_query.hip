@@ -649,6 +649,15 @@ __device__ inline uint32_t writelane_u32(uint32_t v, uint32_t x, int l) {
 }
 #pragma clang diagnostic pop
 
+// fp32 pre-filter distance of the tile and wave kernels (fp32 records, fp32 targets): 3 sub, 1 mul, 2 fma on exact inputs, all
+// terms >= 0 -- relative error < 2^-21.  Never a result: what passes is evaluated again in fp64, unfused.
+__device__ inline float dist2_f32(float qx, float qy, float qz, const RecF& r) {
+  const float dx = qx - r.x, dy = qy - r.y, dz = qz - r.z;
+  return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+}
+template <class Rec> struct IsRecF { static constexpr bool value = false; };
+template <> struct IsRecF<RecF> { static constexpr bool value = true; };
+
 template <class Rec>
 struct WaveScan {
   const Rec* __restrict__ src;
@@ -658,6 +667,16 @@ struct WaveScan {
   uint32_t li;
   double lim_d, bnd_d;         // acceptance limit = min(entry of rank k-1, caller's bound): wave-uniform
   uint32_t lim_i;
+  // fp32 clouds: a step whose 64 records are all beyond the limit ALREADY IN FP32 (most steps of a long scan) skips the fp64 metric
+  // and everything after it.  d32 <= d (1 + 2^-21) (dist2_f32), so a record with d <= lim_d has d32 <= lim32 := lim_d (1 + 2^-20)
+  // rounded to float (nearest: 2^-24 at most the wrong way), plus a slack for fp32 underflow; +inf stays +inf.
+#ifdef PT_NOPRE32
+  static constexpr bool PRE32 = false;                   // (A/B builds: tools/sweep_pend.sh)
+#else
+  static constexpr bool PRE32 = IsRecF<Rec>::value;
+#endif
+  float qf[3], lim32;
+  __device__ __forceinline__ void set_lim32() { lim32 = (float)(lim_d * 1.00000095367431640625) + 1e-30f; }
   int k, lane;
   // candidates set aside (k >= PEND_MIN_K): this wave's 64 slots in LDS and how many are taken (wave-uniform); see offer()
   double* pend_d;
@@ -667,12 +686,24 @@ struct WaveScan {
   uint32_t nv = 0, nn = 0;     // instrumented build: steps of 64 records, nodes entered
 #endif
 
-  __device__ void reset() { ld = INFINITY; li = PT_NOIDX_U; lim_d = bnd_d; lim_i = PT_NOIDX_U; npend = 0; }
+  __device__ void reset() { ld = INFINITY; li = PT_NOIDX_U; lim_d = bnd_d; lim_i = PT_NOIDX_U; npend = 0; set_lim32(); }
   __device__ void refresh() {
     const double kd = readlane_f64(ld, k - 1);
     const uint32_t ki = readlane_u32(li, k - 1);
     if (key_lt_flat(kd, ki, bnd_d, PT_NOIDX_U)) { lim_d = kd; lim_i = ki; }
     else { lim_d = bnd_d; lim_i = PT_NOIDX_U; }
+    set_lim32();
+  }
+  // one step's 64 records: fp32 clouds look at the fp32 distance first
+  __device__ __forceinline__ void step(const Rec& r, bool have) {
+    if constexpr (PRE32) {
+      const bool near32 = have && dist2_f32(qf[0], qf[1], qf[2], r) <= lim32;
+      if (!__ballot(near32)) return;                        // wave-uniform
+    }
+    double d = INFINITY;
+    uint32_t id = PT_NOIDX_U;
+    if (have) { d = dist2(q, r); id = r.id; }
+    offer(d, id);
   }
   // (xd, xi) wave-uniform.  The entries that sort after it are a run of lanes [p, 63] (the list is sorted): they shift up one lane
   // -- DPP moves executed by THOSE lanes only (lane p reads lane p - 1, which is switched off: bound_ctrl hands it a 0 that the
@@ -805,7 +836,10 @@ struct WaveScan {
   }
   // WPF steps of loads are in flight while a step is ranked: with one, every step of 64 records cost a full memory latency (60 us
   // per target at 25 - 35 steps, measured: the steps' arithmetic is ~0.15 us)
-  static constexpr int WPF = 1;
+#ifndef PT_WPF
+#define PT_WPF 1
+#endif
+  static constexpr int WPF = PT_WPF;
   __device__ void range(uint32_t s, uint32_t e) {
     Rec pq[WPF];
 #pragma unroll
@@ -819,13 +853,10 @@ struct WaveScan {
 #pragma unroll
       for (int j = 0; j + 1 < WPF; ++j) pq[j] = pq[j + 1];
       if (p + (uint32_t)(WPF * 64) < e) pq[WPF - 1] = src[p + (uint32_t)(WPF * 64)];
-      double d = INFINITY;
-      uint32_t id = PT_NOIDX_U;
-      if (p < e) { d = dist2(q, r); id = r.id; }
 #ifdef PT_VISITS
       ++nv;
 #endif
-      offer(d, id);
+      step(r, p < e);
     }
   }
   // Up to 64 runs of records as ONE stream: lane j brings its run's first record S and length C (0: none); virtual record v of the
@@ -870,13 +901,10 @@ struct WaveScan {
       for (int j = 0; j + 1 < WPF; ++j) pq[j] = pq[j + 1];
       const uint32_t a = locate(v + (uint32_t)(WPF * 64));
       if (v + (uint32_t)(WPF * 64) < T) pq[WPF - 1] = src[a];
-      double d = INFINITY;
-      uint32_t id = PT_NOIDX_U;
-      if (v < T) { d = dist2(q, r); id = r.id; }
 #ifdef PT_VISITS
       ++nv;
 #endif
-      offer(d, id);
+      step(r, v < T);
     }
   }
   __device__ double gap2(int a, double lo, double hi) const {
@@ -976,6 +1004,7 @@ __global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams g
   W.src = src; W.nodes = ha.nodes; W.k = k; W.lane = lane;
   W.pend_d = pend_d[threadIdx.x >> 6]; W.pend_i = pend_i[threadIdx.x >> 6];
   W.q[0] = (double)tr.x; W.q[1] = (double)tr.y; W.q[2] = (double)tr.z;
+  W.qf[0] = (float)tr.x; W.qf[1] = (float)tr.y; W.qf[2] = (float)tr.z;      // (used by fp32 clouds only, whose targets are fp32 too)
   W.h2 = gp.h * gp.h;
   int c[3];
 #pragma unroll
@@ -1160,10 +1189,6 @@ constexpr int TILE_R = 10, TILE_CELLS = TILE_R * TILE_R * TILE_R;
 // WIDE: k in (24, 32] -- a longer queue for pass 3 (512-thread workgroups: the registers of 12 waves would not hold it)
 template <int K, bool WIDE> struct TileQ { static constexpr int CAP = K == 8 ? 24 : (K == 16 ? 40 : (WIDE ? 64 : 48)), LCAP = K == 8 ? 8 : 16; };
 
-__device__ inline float dist2_f32(float qx, float qy, float qz, const RecF& r) {
-  const float dx = qx - r.x, dy = qy - r.y, dz = qz - r.z;
-  return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));     // a pre-filter only: fused is fine (and both passes use it)
-}
 // LDS read of one staged record as ONE ds_read_b128 (4 LDS cycles per wave-instruction).  Without the empty asm the
 // compiler drops the unused id and emits ds_read_b96, which costs 8 (MI355X_MICROARCH.md, LDS table).
 __device__ inline RecF lds_rec(const RecF* p) {
