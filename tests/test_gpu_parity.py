@@ -429,6 +429,33 @@ def test_logical_slabs_merge_equals_global(pkg, oracle, g):
         p.close()
 
 
+def test_fp16_slabs_of_the_clustered_generator(pkg, oracle):
+    """Config 5 as its multi-GPU run builds it: every slab generates its own part of the clustered fp16 cloud (fp16-resident input
+    with global indices), answers every target, and the G-way merge equals the oracle over the whole cloud."""
+    import torch
+    g, n, m, k, seed = 3, 150000, 4000, 32, 0xC5
+    src = oracle.synth_xyz(seed, 0, n, dist=1, n_total=n, m_total=m).astype(np.float16).astype(np.float32)
+    tgt = oracle.synth_xyz(seed, 1, m, dist=1, n_total=n, m_total=m).astype(np.float16).astype(np.float32)
+    want = oracle.KdTree(src.astype(np.float64)).query(tgt.astype(np.float64), k)
+    bounds = np.concatenate([[-math.inf], np.quantile(src[0], np.arange(1, g) / g), [math.inf]])
+    li = torch.empty((g, m, k), dtype=torch.int32, device="cuda"); ld = torch.empty((g, m, k), dtype=torch.float64, device="cuda")
+    tx = torch.from_numpy(tgt).cuda()
+    ctxs = []
+    for s in range(g):
+        p = pkg.PointsTransfer(device=0, k_hint=k)
+        p.build_synth(n, seed, dist=pkg.capi.DIST_CLUSTERED, xyz_type=pkg.F16, slab_axis=0, slab_lo=bounds[s], slab_hi=bounds[s + 1])
+        ctxs.append(p)
+    assert sum(p.num_source for p in ctxs) == n
+    for s, p in enumerate(ctxs):
+        p.query_dev(tx, pkg.F32, m, k, li[s], ld[s])
+    oi = torch.empty((m, k), dtype=torch.int32, device="cuda"); od = torch.empty((m, k), dtype=torch.float64, device="cuda")
+    ctxs[0].merge_candidates_dev(li, ld, g, m, k, oi, od)
+    torch.cuda.synchronize()
+    _check_exact((oi.cpu().numpy().view(np.uint32), od.cpu().numpy()), want, "fp16 slabs")
+    for p in ctxs:
+        p.close()
+
+
 # ---- BASELINE config 2 at full size: size-independent properties + sampled exactness ----------------------------
 def test_full_size_c2_properties(pkg, oracle):
     import torch
