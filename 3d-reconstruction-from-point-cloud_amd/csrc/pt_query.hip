@@ -1964,7 +1964,8 @@ void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* c
   } else {
     if (k <= 8) PT_TILE_LAUNCH(8, PT_TILE_CAP_LARGE, 768, false);
     else if (k <= 16) PT_TILE_LAUNCH(16, PT_TILE_CAP_LARGE, 768, false);
-    else if (k <= 24) PT_TILE_LAUNCHC(32, PT_TILE_CAP_LARGE, 768, false, 24);       // the reference's K = 20 (src/pointsTransfer.cpp:128)
+    else if (k <= 20) PT_TILE_LAUNCHC(32, PT_TILE_CAP_LARGE, 768, false, 20);       // the reference's K = 20 (src/pointsTransfer.cpp:128): a chain of exactly 20
+    else if (k <= 24) PT_TILE_LAUNCHC(32, PT_TILE_CAP_LARGE, 768, false, 24);
     else PT_TILE_LAUNCH(32, PT_TILE_CAP_LARGE, 768, false);
   }
 #undef PT_TILE_LAUNCH
