@@ -8,7 +8,8 @@
 // Cell pruning is Distance::min_distance_to_rectangle (reference src/Distance.h:27-57) applied to cell
 // boxes; ring termination is the same bound applied to the faces of the box already scanned.
 //
-// Two kernels, both exact:
+// Three kernels, all exact (a third, knn_wave_kernel -- ONE WAVE PER TARGET, for dense neighbourhoods of clouds with strong density
+// contrast, k > 16 leftovers of the tile kernel and surfaces -- sits between the two halves):
 //   knn_tile_kernel  (second half of this file) fp32 clouds, unbounded queries, k <= 32 -- the throughput path.  One
 //                    workgroup per 8^3-cell block stages the 10^3-cell region around it in LDS and ranks it with a DPP quad
 //                    per target: fp32 bound -> queue -> exact fp64 re-rank.  What ring 1 cannot settle goes to a todo list.
@@ -722,7 +723,7 @@ struct WaveScan {
   }
   // Many candidates at once (the first steps of a target: with fewer than k points seen every record is one): sort the 64 candidate
   // slots across the lanes (bitonic, 21 exchange stages), take the 64 smallest of list and candidates (list[i] against candidate
-  // [63 - i]) and sort that bitonic sequence (6 stages) -- ~400 instructions whatever the number of candidates, against ~60 for
+  // [63 - i]) and sort that bitonic sequence (6 stages) -- ~500 instructions whatever the number of candidates, against ~35 for
   // each one-by-one insertion.  Keys are distinct (ids) except the empty slots (+inf, NOIDX), whose order does not matter.
   // The exchanges never touch the LDS: partner lane ^ 1, ^ 2 by DPP quad permutes, ^ 4 by two bank-masked row shifts, ^ 8 by a row
   // rotation, ^ 16 and ^ 32 by gfx950's v_permlane16_swap / v_permlane32_swap (both copies of the value go in; each lane picks the
