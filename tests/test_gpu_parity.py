@@ -667,6 +667,24 @@ def test_cell_side_beyond_fp32_range(pkg, oracle):
     assert np.array_equal(idx, wi) and np.array_equal(d2, wd)
 
 
+@pytest.mark.parametrize("scale", [1e-19, 1e-12, 1e18])
+def test_wave_kernel_fp32_prefilter_at_extreme_scales(pkg, oracle, scale):
+    """The wave kernel's fp32 pre-filter where fp32 squares underflow (1e-19: d2 ~ 1e-40, denormal or zero in fp32) or overflow
+    (1e18: d2 ~ 1e36 - 1e38, next to FLT_MAX): it may only ever let MORE through than the exact test, never less."""
+    rng = np.random.default_rng(int(-np.log10(scale)) + 40)
+    base = rng.random((3, 30000))
+    base[:, 5000:9000] = base[:, [77]] + 1e-3 * rng.standard_normal((3, 4000))      # a clump (dense cell: long scans, many candidates)
+    src = (base * scale).astype(np.float32)
+    tgt = np.concatenate([src[:, 5000:5300], (rng.random((3, 300)) * scale).astype(np.float32)], axis=1)
+    with pkg.PointsTransfer(device=0, k_hint=20) as p:
+        p.set_param("wave_force", 1)
+        p.build(src)
+        idx, d2 = p.query(tgt, 20)
+        assert p.stats()["n_wave"] > 0
+    wi, wd = oracle.knn_bruteforce(src.astype(np.float64), tgt.astype(np.float64), 20)
+    assert np.array_equal(idx, wi) and np.array_equal(d2, wd)
+
+
 @pytest.mark.parametrize("k,mode,tile", [(8, 0, 1), (8, 1, 1), (16, 0, 1), (20, 1, 1), (32, 0, 1), (8, 1, 0)])
 def test_fused_query_blend_matches_the_two_calls(pkg, oracle, k, mode, tile):
     """pt_query_blend_resident = pt_query_resident + pt_blend_dev: identical neighbours and distances, blended attributes
