@@ -168,7 +168,7 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
   const size_t nmac = nblocks / PT_MACRO_BLOCKS, ngrp = (nmac + ((size_t)1 << gsh) - 1) >> gsh, nmacP = ngrp << gsh;
   const size_t nchunks = pt_sort_num_chunks(npoints, rec_size), nbins1 = ngrp + 1;
   const size_t chunk_words = nblocks > PT_MAXBINS ? (nchunks + 1) * nbins1 + (nchunks / 64 + 2) * nbins1 : 0;
-  const size_t bid_words = nblocks > PT_MAXBINS && !gsh ? ((size_t)npoints + 3) / 2 + 2 : 0;      // u16 per point, two-level sorts only
+  const size_t bid_words = nblocks > PT_MAXBINS && !gsh ? ((size_t)npoints + 3) / 2 + 12 : 0;     // u16 per point, two-level sorts only; 16-byte aligned, 16 bytes of slack (read 8 at a time)
   const size_t mac_words = gsh ? (nmacP + 8) * 4 : 0;
   RES(c, mem, (words + chunk_words + bid_words + mac_words + 16) * sizeof(uint32_t));
   uint32_t* p = (uint32_t*)mem.p;
@@ -184,8 +184,9 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
   tb.scan_tmp = p; p += (size_t)nblocks / 2048 + 16;
   tb.chunk_hist = p; p += (nchunks + 1) * nbins1;
   tb.chunk_gsum = p; p += (nchunks / 64 + 2) * nbins1;
+  if (bid_words) p += (4 - ((uintptr_t)p / sizeof(uint32_t)) % 4) % 4;                  // (at most 3 of bid_words' spare words)
   tb.bid = bid_words ? (uint16_t*)p : nullptr;
-  p += bid_words;
+  p += bid_words ? bid_words - 4 : 0;
   tb.countsM = tb.startM = tb.cursorM = tb.tile_firstM = nullptr;
   if (gsh) { tb.countsM = p; p += nmacP + 8; tb.startM = p; p += nmacP + 8; tb.cursorM = p; p += nmacP + 8; tb.tile_firstM = p; p += nmacP + 8; }
   tb.occupied = nullptr;

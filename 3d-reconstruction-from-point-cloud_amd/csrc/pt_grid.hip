@@ -509,10 +509,23 @@ __global__ __launch_bounds__(WG) void hist_bid_kernel(const uint16_t* __restrict
       __syncthreads();
       cur_seg = (int)seg;
     }
+    // eight ids per 16-byte load (the table is 16-byte aligned and padded: pt_api.hip make_tables), from the aligned group the tile
+    // starts in; the ids outside [s, e) are masked.  Two bytes per lane and load -- the first form of this -- moved 128 bytes per
+    // wave-instruction.
+    static_assert(TILE % 8 == 0 && (TILE + 8) <= 3 * WG * 8, "three trips cover a tile and its misalignment");
+    const uint32_t a = s & ~7u;
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-      const uint32_t i = s + j * WG + threadIdx.x;
-      if (i < e) atomicAdd(&hist[bid[i]], 1u);
+    for (int j = 0; j < 3; ++j) {
+      const uint32_t g = a + ((uint32_t)j * WG + threadIdx.x) * 8u;
+      if (g < e) {
+        const uint4 v = *reinterpret_cast<const uint4*>(bid + g);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const uint32_t i = g + (uint32_t)q, id = (w[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu;
+          if (i >= s && i < e) atomicAdd(&hist[id], 1u);
+        }
+      }
     }
   }
   __syncthreads();
