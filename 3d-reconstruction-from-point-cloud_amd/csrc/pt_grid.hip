@@ -353,8 +353,7 @@ __global__ __launch_bounds__(WG) void hist_chunk_kernel(Loader in, GridParams gp
   using CT = decltype(in.load(0).x);                 // min / max in the cloud's own type: exact, and cheap for fp32
   CT tmn[3] = {(CT)INFINITY, (CT)INFINITY, (CT)INFINITY}, tmx[3] = {(CT)-INFINITY, (CT)-INFINITY, (CT)-INFINITY};
   bool nan_seen = false;
-  for (uint32_t i = (uint32_t)base + threadIdx.x; i < end; i += WG) {
-    const auto r = in.load(i);
+  auto take = [&](const decltype(in.load(0))& r) {
     atomicAdd(&hist[local_bin(bs, block_of_rec(gp, r))], 1u);
     if (bbox6) {
       tmn[0] = r.x < tmn[0] ? r.x : tmn[0]; tmx[0] = r.x > tmx[0] ? r.x : tmx[0];
@@ -362,7 +361,18 @@ __global__ __launch_bounds__(WG) void hist_chunk_kernel(Loader in, GridParams gp
       tmn[2] = r.z < tmn[2] ? r.z : tmn[2]; tmx[2] = r.z > tmx[2] ? r.z : tmx[2];
       nan_seen |= (r.x != r.x) | (r.y != r.y) | (r.z != r.z);          // the comparisons above ignore a NaN
     }
+  };
+  // HB records (their 3 HB loads) in flight per thread; one at a time the pass ran at 4.3 TB/s, a plain reduction of the same bytes at 5
+  constexpr int HB = 4;
+  uint32_t i = (uint32_t)base + threadIdx.x;
+  for (; (uint64_t)i + (HB - 1) * WG < end; i += HB * WG) {
+    decltype(in.load(0)) r[HB];
+#pragma unroll
+    for (int j = 0; j < HB; ++j) r[j] = in.load(i + j * WG);
+#pragma unroll
+    for (int j = 0; j < HB; ++j) take(r[j]);
   }
+  for (; i < end; i += WG) take(in.load(i));
   if (bbox6) {
     if (nan_seen) tmn[0] = (CT)-INFINITY;                               // "not finite" for the host's check of the verified box
     double mn[3] = {(double)tmn[0], (double)tmn[1], (double)tmn[2]}, mx[3] = {(double)tmx[0], (double)tmx[1], (double)tmx[2]};
