@@ -982,8 +982,14 @@ struct WaveScan {
   }
 };
 
+#ifndef PT_WV_MINW_H
+#define PT_WV_MINW_H 6
+#endif
+#ifndef PT_WV_MINW
+#define PT_WV_MINW 8
+#endif
 template <class Rec, bool HIER>
-__global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams gp, const Rec* __restrict__ src, const uint32_t* __restrict__ cs, const Rec* __restrict__ tgt,
+__global__ __launch_bounds__(WG, HIER ? PT_WV_MINW_H : PT_WV_MINW) void knn_wave_kernel(GridParams gp, const Rec* __restrict__ src, const uint32_t* __restrict__ cs, const Rec* __restrict__ tgt,
                                                       uint32_t m, int k, const double* __restrict__ bound2, uint32_t* __restrict__ out_idx,
                                                       double* __restrict__ out_d2, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_n,
                                                       HierArgs ha, WaveBlend wb) {
@@ -992,7 +998,7 @@ __global__ __launch_bounds__(WG, HIER ? 4 : 1) void knn_wave_kernel(GridParams g
   // advance through the list together (one contiguous eighth per XCD: the dense parts of the cloud end up on a few XCDs, 1.6 x slower).
   const uint32_t count = list ? *list_n : m;
   const uint32_t j = blockIdx.x >> 3, wgl = ((j / WV_RUN) * 8u + (blockIdx.x & 7u)) * WV_RUN + j % WV_RUN;
-  const uint32_t wid = wgl * 4u + (threadIdx.x >> 6);
+  const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wgl * 4u + (threadIdx.x >> 6)));       // wave-uniform by construction: said so, the target and everything derived from it live in SGPRs
   if (wid >= count) return;                                 // whole waves leave together
   const int lane = threadIdx.x & 63;
   const Rec tr = tgt[list ? list[wid] : wid];

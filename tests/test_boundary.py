@@ -119,15 +119,18 @@ def test_metric_has_no_fma_in_query_kernels():
         checked += 1
         assert "v_fma_f64" not in b and "v_fmac_f64" not in b, name
     assert checked >= 10
-    # no scratch spills in the hot kernels.  The one exception: the HIER = true instantiations of the group and wave kernels (clouds with
-    # refined cells only): their register budget is capped for occupancy and the three-level descent, cold code, spills a little.
+    # no scratch spills in the hot kernels.  Two exceptions, both measured: the HIER = true instantiations of the group and wave kernels
+    # (clouds with refined cells only): their register budget is capped for occupancy and the three-level descent, cold code, spills a
+    # little; and the wave kernel's plain variant, held to 64 VGPRs for eight waves per SIMD (a handful of cold registers in scratch:
+    # 280 ms against 297 at seven waves without spills).
     for b in s.split("; -- Begin function ")[1:]:
         name = b.split("\n", 1)[0].strip()
         m = re.search(r"ScratchSize: (\d+)", b)
         if m is None or "s_endpgm" not in b:
             continue
         hier = ("knn_kernel" in name or "knn_wave_kernel" in name) and re.search(r"ELb1EEEv", name) is not None
-        assert int(m.group(1)) == 0 or (hier and int(m.group(1)) <= 512), (name, m.group(1))
+        wave = "knn_wave_kernel" in name
+        assert int(m.group(1)) == 0 or (hier and int(m.group(1)) <= 512) or (wave and int(m.group(1)) <= 64), (name, m.group(1))
 
 
 def test_png_writer_roundtrip(tmp_path):
