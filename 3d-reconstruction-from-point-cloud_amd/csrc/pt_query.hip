@@ -1657,19 +1657,29 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
     if (active) {
       if (done) {
         const size_t row = (size_t)tr.id * (size_t)k;
+        // (BLEND) the k neighbours' attribute records are gathered right here -- ALL of a lane's gathers issued before anything
+        // waits for one, and before the result stores below (the memory counter is in order: a load behind a store waits for it).
+        // Gather, wait, accumulate per neighbour -- the first form of this -- cost a lane six random-access latencies in a row.
+        Attr at[BLEND ? TILE_QCAP / 4 : 1];
+        if constexpr (BLEND) {
+          // (unconditional loads -- an entry that is not among the k reads record 0, one cached line for the whole chip -- because
+          // behind a branch each the compiler still put a full wait between them)
+#pragma unroll
+          for (int j = 0; j < TILE_QCAP / 4; ++j)
+            at[j] = pt_gather_attr(bl.attr, (oi[j] != PT_NOIDX_U && rk[j] < k && oi[j] < bl.n_attr) ? oi[j] : 0u);
+        }
 #pragma unroll
         for (int j = 0; j < TILE_QCAP / 4; ++j)
           if (oi[j] != PT_NOIDX_U && rk[j] < k) { out_idx[row + rk[j]] = oi[j]; if (out_d2) out_d2[row + rk[j]] = od[j]; }
         for (uint32_t sl = nq + ql; sl < (uint32_t)k; sl += 4) { out_idx[row + sl] = PT_NOIDX_U; if (out_d2) out_d2[row + sl] = INFINITY; }
         if constexpr (BLEND) {
-          // the k neighbours' attribute records are gathered right here (their latency hides under the ranking of the
-          // workgroup's other waves) and blended as pt_attr.hip's blend_kernel does: fp64 sums, then one normalisation
+          // blended as pt_attr.hip's blend_kernel does: fp64 sums, then one normalisation
           double ws = 0.0, c0 = 0.0, c1 = 0.0, c2 = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0;
 #pragma unroll
           for (int j = 0; j < TILE_QCAP / 4; ++j) {
             if (oi[j] != PT_NOIDX_U && rk[j] < k && oi[j] < bl.n_attr) {
               const double w = (bl.mode == 1) ? 1.0 / (od[j] + 1e-12) : 1.0;
-              const Attr a = pt_gather_attr(bl.attr, oi[j]);
+              const Attr a = at[j];
               ws += w;
               c0 += w * (double)(a.rgba & 0xFFu); c1 += w * (double)((a.rgba >> 8) & 0xFFu); c2 += w * (double)((a.rgba >> 16) & 0xFFu);
               n0 += w * (double)a.nx; n1 += w * (double)a.ny; n2 += w * (double)a.nz;
