@@ -143,14 +143,24 @@ __global__ __launch_bounds__(WG) void pack_attr_kernel(const uint8_t* __restrict
 __device__ inline void blend_one(const uint32_t* __restrict__ idx, const double* __restrict__ d2, uint32_t t, int k, int mode,
                                  const Attr* __restrict__ attr, uint32_t n_attr, float* __restrict__ rgb_out, float* __restrict__ nrm_out) {
   double wsum = 0.0, c[3] = {0, 0, 0}, nn[3] = {0, 0, 0};
-  for (int j = 0; j < k; ++j) {
-    const uint32_t id = idx[(size_t)t * k + j];
-    if (id == PT_NOIDX_U || id >= n_attr) continue;
-    const double w = (mode == 1) ? 1.0 / (d2[(size_t)t * k + j] + 1e-12) : 1.0;
-    const Attr a = pt_gather_attr(attr, id);
-    wsum += w;
-    c[0] += w * (double)(a.rgba & 0xFFu); c[1] += w * (double)((a.rgba >> 8) & 0xFFu); c[2] += w * (double)((a.rgba >> 16) & 0xFFu);
-    nn[0] += w * (double)a.nx; nn[1] += w * (double)a.ny; nn[2] += w * (double)a.nz;
+  // four neighbours' records in flight per thread (one by one, a thread waited k random-access latencies in a row); the sums keep
+  // their order.  A missing neighbour reads record 0 (cached) instead of branching around its load.
+  constexpr int GB = 4;
+  for (int j0 = 0; j0 < k && n_attr; j0 += GB) {
+    uint32_t id[GB];
+    Attr a[GB];
+#pragma unroll
+    for (int q = 0; q < GB; ++q) id[q] = j0 + q < k ? idx[(size_t)t * k + j0 + q] : PT_NOIDX_U;
+#pragma unroll
+    for (int q = 0; q < GB; ++q) a[q] = pt_gather_attr(attr, (id[q] != PT_NOIDX_U && id[q] < n_attr) ? id[q] : 0u);
+#pragma unroll
+    for (int q = 0; q < GB; ++q) {
+      if (id[q] == PT_NOIDX_U || id[q] >= n_attr) continue;
+      const double w = (mode == 1) ? 1.0 / (d2[(size_t)t * k + j0 + q] + 1e-12) : 1.0;
+      wsum += w;
+      c[0] += w * (double)(a[q].rgba & 0xFFu); c[1] += w * (double)((a[q].rgba >> 8) & 0xFFu); c[2] += w * (double)((a[q].rgba >> 16) & 0xFFu);
+      nn[0] += w * (double)a[q].nx; nn[1] += w * (double)a[q].ny; nn[2] += w * (double)a[q].nz;
+    }
   }
   if (wsum > 0.0) {
     const double iw = 1.0 / wsum;
