@@ -275,22 +275,31 @@ __device__ inline void pca_one(const uint32_t* __restrict__ idx, uint32_t t, int
   double mn[3] = {0, 0, 0}, sd[3] = {0, 0, 0}, o[3] = {0, 0, 0};
   double cv[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   int ke = 0;
-  for (int j = 0; j < k; ++j) {
-    const uint32_t id = idx[(size_t)t * k + j];
-    if (id == PT_NOIDX_U || id >= n) continue;
-    double p[3];
-    float an[3];
-    fetch(id, p, an);
-    if (ke == 0) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
-    const double d[3] = {p[0] - o[0], p[1] - o[1], p[2] - o[2]};
+  // four neighbours' records in flight per thread, consumed in order (as blend_one; a missing neighbour fetches record 0)
+  constexpr int GB = 4;
+  for (int j0 = 0; j0 < k && n; j0 += GB) {
+    uint32_t id[GB];
+    double pq[GB][3];
+    float aq[GB][3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      sd[a] += d[a];
+    for (int q = 0; q < GB; ++q) id[q] = j0 + q < k ? idx[(size_t)t * k + j0 + q] : PT_NOIDX_U;
 #pragma unroll
-      for (int b = 0; b < 3; ++b) cv[a][b] += d[a] * d[b];
+    for (int q = 0; q < GB; ++q) fetch((id[q] != PT_NOIDX_U && id[q] < n) ? id[q] : 0u, pq[q], aq[q]);
+#pragma unroll
+    for (int q = 0; q < GB; ++q) {
+      if (id[q] == PT_NOIDX_U || id[q] >= n) continue;
+      const double* p = pq[q];
+      if (ke == 0) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+      const double d[3] = {p[0] - o[0], p[1] - o[1], p[2] - o[2]};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        sd[a] += d[a];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) cv[a][b] += d[a] * d[b];
+      }
+      ++ke;
+      if (has_attr) { mn[0] += (double)aq[q][0]; mn[1] += (double)aq[q][1]; mn[2] += (double)aq[q][2]; }
     }
-    ++ke;
-    if (has_attr) { mn[0] += (double)an[0]; mn[1] += (double)an[1]; mn[2] += (double)an[2]; }
   }
   float* o3 = nrm_out + 3 * (size_t)t;
   if (ke < 3) { o3[0] = 0.f; o3[1] = 0.f; o3[2] = 1.f; return; }
