@@ -1370,6 +1370,11 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
     }
     return;
   }
+  // the first round's target of this quad: requested here so that it arrives during the staging (loaded where it is first used,
+  // every round began with a memory latency that nothing else of the wave could cover)
+  RecF tr_first;
+  tr_first.x = tr_first.y = tr_first.z = 0.f; tr_first.id = 0;
+  if constexpr (!DBL) { if (ts + (threadIdx.x >> 2) < te) tr_first = tgt[ts + (threadIdx.x >> 2)]; }
   // ---- B: stage the region, HBM -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, per-lane
   //         source address; no staging registers).  Cells x = 1..8 of a region row are one contiguous run in HBM and in
   //         LDS: two DMA instructions per row (<= 128 records) with wave-uniform (scalar) addresses; the 200 halo cells
@@ -1449,7 +1454,8 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
     if constexpr (DBL) {
       if (active) { const RecD td = dd.tgt[t]; q[0] = td.x; q[1] = td.y; q[2] = td.z; tr.x = (float)td.x; tr.y = (float)td.y; tr.z = (float)td.z; tr.id = td.id; }
     } else {
-      if (active) tr = tgt[t];
+      if (base == ts) tr = tr_first;                    // (workgroup-uniform test)
+      else if (active) tr = tgt[t];
 #if defined(PT_ABLATE) && PT_ABLATE == 4
       tr.x = (float)((double)tr.x + hshift[0]); tr.y = (float)((double)tr.y + hshift[1]); tr.z = (float)((double)tr.z + hshift[2]);
 #endif
