@@ -263,10 +263,20 @@ __global__ __launch_bounds__(WG) void hist_kernel(Loader in, GridParams gp, BinS
       __syncthreads();
       cur_seg = (int)seg;
     }
+    constexpr int HBK = ITEMS < 8 ? ITEMS : 8;             // eight records' loads in flight, then their bins (see scatter_kernel)
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-      const uint32_t i = s + j * WG + threadIdx.x;
-      if (i < e) atomicAdd(&hist[local_bin(bs, block_of_rec(gp, in.load(i)))], 1u);
+    for (int j0 = 0; j0 < ITEMS; j0 += HBK) {
+      decltype(in.load(0)) r[HBK];
+#pragma unroll
+      for (int j = 0; j < HBK; ++j) {
+        const uint32_t i = s + (j0 + j) * WG + threadIdx.x;
+        if (i < e) r[j] = in.load(i);
+      }
+#pragma unroll
+      for (int j = 0; j < HBK; ++j) {
+        const uint32_t i = s + (j0 + j) * WG + threadIdx.x;
+        if (i < e) atomicAdd(&hist[local_bin(bs, block_of_rec(gp, r[j]))], 1u);
+      }
     }
   }
   __syncthreads();
@@ -294,11 +304,17 @@ __global__ __launch_bounds__(SW) void scatter_kernel(Loader in, typename Loader:
 
   Rec r[ITEMS];
   uint32_t lb[ITEMS], rank[ITEMS];
+  // every load of the tile is issued before the first record is binned (in one loop, the 16-byte record loads came out with a full
+  // wait after each: ITEMS memory latencies in a row per tile)
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const uint32_t i = s + j * SW + threadIdx.x;
+    if (i < e) r[j] = in.load(i);
+  }
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
     const uint32_t i = s + j * SW + threadIdx.x;
     if (i < e) {
-      r[j] = in.load(i);
       lb[j] = local_bin(bs, block_of_rec(gp, r[j]));
       rank[j] = atomicAdd(&binA[lb[j]], 1u);
     }
@@ -577,10 +593,14 @@ __global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ i
   uint32_t lc[FITEMS];
   if (in_regs) {
 #pragma unroll
+    for (int j = 0; j < FITEMS; ++j) {                     // (all loads first: see scatter_kernel)
+      const uint32_t i = s + j * FWG + threadIdx.x;
+      if (i < e) r[j] = in[i];
+    }
+#pragma unroll
     for (int j = 0; j < FITEMS; ++j) {
       const uint32_t i = s + j * FWG + threadIdx.x;
       if (i < e) {
-        r[j] = in[i];
         int cx, cy, cz;
         pt_cell_of(gp, r[j], cx, cy, cz);
         lc[j] = pt_local_cell(cx, cy, cz);
