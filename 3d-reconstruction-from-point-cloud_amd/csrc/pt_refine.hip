@@ -101,23 +101,12 @@ __global__ __launch_bounds__(RW) void refine_nodes_kernel(GridParams gp, Rec* __
   uint32_t sc[RITEMS];
   if (in_regs) {
 #pragma unroll
-    for (int j = 0; j < RITEMS; ++j) {                     // (all loads first: one loop with the LDS atomics waited for each in turn)
-      const uint32_t i = s + j * RW + threadIdx.x;
-      if (i < e) r[j] = rec[i];
-    }
-#pragma unroll
     for (int j = 0; j < RITEMS; ++j) {
       const uint32_t i = s + j * RW + threadIdx.x;
-      if (i < e) { sc[j] = subcell_of(gp, r[j], ox, oy, oz, inv); atomicAdd(&cnt[sc[j]], 1u); }
+      if (i < e) { r[j] = rec[i]; sc[j] = subcell_of(gp, r[j], ox, oy, oz, inv); atomicAdd(&cnt[sc[j]], 1u); }
     }
   } else {
-    for (uint32_t i0 = s + threadIdx.x; i0 < e; i0 += 4 * RW) {      // four records in flight per thread
-      Rec v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) if ((uint64_t)i0 + q * RW < e) v[q] = rec[i0 + q * RW];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) if ((uint64_t)i0 + q * RW < e) atomicAdd(&cnt[subcell_of(gp, v[q], ox, oy, oz, inv)], 1u);
-    }
+    for (uint32_t i = s + threadIdx.x; i < e; i += RW) atomicAdd(&cnt[subcell_of(gp, rec[i], ox, oy, oz, inv)], 1u);
   }
   __syncthreads();
   const uint32_t c0 = cnt[threadIdx.x];
@@ -149,22 +138,13 @@ __global__ __launch_bounds__(RW) void refine_nodes_kernel(GridParams gp, Rec* __
       if (i < e) rec[s + atomicAdd(&cnt[sc[j]], 1u)] = r[j];
     }
   } else {                                                  // big node: through the scratch array, then back (one workgroup owns the range)
-    for (uint32_t i0 = s + threadIdx.x; i0 < e; i0 += 4 * RW) {
-      Rec v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) if ((uint64_t)i0 + q * RW < e) v[q] = rec[i0 + q * RW];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) if ((uint64_t)i0 + q * RW < e) tmp[s + atomicAdd(&cnt[subcell_of(gp, v[q], ox, oy, oz, inv)], 1u)] = v[q];
+    for (uint32_t i = s + threadIdx.x; i < e; i += RW) {
+      const Rec v = rec[i];
+      tmp[s + atomicAdd(&cnt[subcell_of(gp, v, ox, oy, oz, inv)], 1u)] = v;
     }
     __threadfence();
     __syncthreads();
-    for (uint32_t i0 = s + threadIdx.x; i0 < e; i0 += 4 * RW) {
-      Rec v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) if ((uint64_t)i0 + q * RW < e) v[q] = tmp[i0 + q * RW];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) if ((uint64_t)i0 + q * RW < e) rec[i0 + q * RW] = v[q];
-    }
+    for (uint32_t i = s + threadIdx.x; i < e; i += RW) rec[i] = tmp[i];
   }
 }
 
