@@ -45,12 +45,26 @@ struct PlanarLoader {
     r.id = gidx ? gidx[i] : i;
     return r;
   }
+  // the same with the question "is there an index array" answered by the caller, once per tile: inside load() the optional fourth
+  // load lands in one scratch register per record, and the wait that protects it waits for the whole record (ISA: s_waitcnt
+  // vmcnt(0) after every record's loads, whether or not there is an index array)
+  __device__ bool has_ids() const { return gidx != nullptr; }
+  template <bool IDS>
+  __device__ Rec load_t(uint32_t i) const {
+    Rec r;
+    r.x = pt_widen(x[i]); r.y = pt_widen(y[i]); r.z = pt_widen(z[i]);
+    if constexpr (IDS) r.id = gidx[i]; else r.id = i;
+    return r;
+  }
 };
 template <class R>
 struct RecLoader {
   using Rec = R;
   const R* p;
   __device__ Rec load(uint32_t i) const { return p[i]; }
+  __device__ bool has_ids() const { return false; }
+  template <bool IDS>
+  __device__ Rec load_t(uint32_t i) const { return p[i]; }
 };
 
 struct BinSpec {
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(SW) void scatter_kernel(Loader in, typename Loader:
   __shared__ Rec stage[TILE];
 
   uint32_t seg, s, e;
-  if (!tile_range(seg_start, tile_first, nseg, blockIdx.x, TILE, seg, s, e)) return;
+  if (!tile_range(seg_start, tile_first, nseg, blockIdx.x, TILE, seg, s, e) || e <= s) return;      // (workgroup-uniform; tiles are never empty)
   for (int b = threadIdx.x; b < PT_MAXBINS; b += SW) binA[b] = 0;
   __syncthreads();
 
@@ -306,10 +320,12 @@ __global__ __launch_bounds__(SW) void scatter_kernel(Loader in, typename Loader:
   uint32_t lb[ITEMS], rank[ITEMS];
   // every load of the tile is issued before the first record is binned (in one loop, the 16-byte record loads came out with a full
   // wait after each: ITEMS memory latencies in a row per tile)
+  if (in.has_ids()) {                                        // (workgroup-uniform; see PlanarLoader::load_t and scatter_chunk_kernel)
 #pragma unroll
-  for (int j = 0; j < ITEMS; ++j) {
-    const uint32_t i = s + j * SW + threadIdx.x;
-    if (i < e) r[j] = in.load(i);
+    for (int j = 0; j < ITEMS; ++j) r[j] = in.template load_t<true>(min(s + j * SW + threadIdx.x, e - 1u));
+  } else {
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) r[j] = in.template load_t<false>(min(s + j * SW + threadIdx.x, e - 1u));
   }
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
@@ -468,11 +484,21 @@ __global__ __launch_bounds__(SW) void scatter_chunk_kernel(Loader in, typename L
     __syncthreads();
     Rec r[ITEMS];
     uint32_t lb[ITEMS], rank[ITEMS];
+    // all of the tile's loads first (see scatter_kernel: in one loop with the binning, each record's three loads were waited for
+    // before the next record's were issued -- eight memory latencies in a row per tile)
+    // (unconditional loads, the index clamped into the tile: a load behind `if (i < e)` is copied into its array slot at the join,
+    //  and that copy waits for it on the spot)
+    if (in.has_ids()) {                                      // (workgroup-uniform)
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) r[j] = in.template load_t<true>(min(s + j * SW + threadIdx.x, e - 1u));
+    } else {
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) r[j] = in.template load_t<false>(min(s + j * SW + threadIdx.x, e - 1u));
+    }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       const uint32_t i = s + j * SW + threadIdx.x;
       if (i < e) {
-        r[j] = in.load(i);
         lb[j] = local_bin(bs, block_of_rec(gp, r[j]));
         rank[j] = atomicAdd(&binA[lb[j]], 1u);
       }
@@ -593,10 +619,7 @@ __global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ i
   uint32_t lc[FITEMS];
   if (in_regs) {
 #pragma unroll
-    for (int j = 0; j < FITEMS; ++j) {                     // (all loads first: see scatter_kernel)
-      const uint32_t i = s + j * FWG + threadIdx.x;
-      if (i < e) r[j] = in[i];
-    }
+    for (int j = 0; j < FITEMS; ++j) r[j] = in[min(s + j * FWG + threadIdx.x, e - 1u)];     // (all loads first, unconditional: see scatter_chunk_kernel)
 #pragma unroll
     for (int j = 0; j < FITEMS; ++j) {
       const uint32_t i = s + j * FWG + threadIdx.x;
