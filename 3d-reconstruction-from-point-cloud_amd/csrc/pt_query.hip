@@ -1663,32 +1663,46 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
     if (active) {
       if (done) {
         const size_t row = (size_t)tr.id * (size_t)k;
-        // (BLEND) the k neighbours' attribute records are gathered right here -- ALL of a lane's gathers issued before anything
-        // waits for one, and before the result stores below (the memory counter is in order: a load behind a store waits for it).
+        // (BLEND) the k neighbours' attribute records are gathered right here, GB of a lane's gathers issued before anything waits
+        // for one, the first group before the result stores (the memory counter is in order: a load behind a store waits for it).
         // Gather, wait, accumulate per neighbour -- the first form of this -- cost a lane six random-access latencies in a row.
-        Attr at[BLEND ? TILE_QCAP / 4 : 1];
-        if constexpr (BLEND) {
-          // (unconditional loads -- an entry that is not among the k reads record 0, one cached line for the whole chip -- because
-          // behind a branch each the compiler still put a full wait between them)
+        // GB: all six entries at k <= 8, four at a time beyond (registers); the fp64 + blend variants have none left and keep
+        // gathering one by one.  The loads are unconditional -- an entry that is not among the k reads record 0, one cached line
+        // for the whole chip -- because behind a branch each the compiler still put a full wait between them.
+        constexpr int NE = TILE_QCAP / 4;
+        constexpr int GB = (BLEND && !DBL) ? (NE <= 6 ? NE : 4) : 1;
+        auto store_results = [&]() {
 #pragma unroll
-          for (int j = 0; j < TILE_QCAP / 4; ++j)
-            at[j] = pt_gather_attr(bl.attr, (oi[j] != PT_NOIDX_U && rk[j] < k && oi[j] < bl.n_attr) ? oi[j] : 0u);
-        }
-#pragma unroll
-        for (int j = 0; j < TILE_QCAP / 4; ++j)
-          if (oi[j] != PT_NOIDX_U && rk[j] < k) { out_idx[row + rk[j]] = oi[j]; if (out_d2) out_d2[row + rk[j]] = od[j]; }
-        for (uint32_t sl = nq + ql; sl < (uint32_t)k; sl += 4) { out_idx[row + sl] = PT_NOIDX_U; if (out_d2) out_d2[row + sl] = INFINITY; }
+          for (int j = 0; j < NE; ++j)
+            if (oi[j] != PT_NOIDX_U && rk[j] < k) { out_idx[row + rk[j]] = oi[j]; if (out_d2) out_d2[row + rk[j]] = od[j]; }
+          for (uint32_t sl = nq + ql; sl < (uint32_t)k; sl += 4) { out_idx[row + sl] = PT_NOIDX_U; if (out_d2) out_d2[row + sl] = INFINITY; }
+        };
+        if constexpr (!BLEND) store_results();
         if constexpr (BLEND) {
           // blended as pt_attr.hip's blend_kernel does: fp64 sums, then one normalisation
           double ws = 0.0, c0 = 0.0, c1 = 0.0, c2 = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0;
 #pragma unroll
-          for (int j = 0; j < TILE_QCAP / 4; ++j) {
-            if (oi[j] != PT_NOIDX_U && rk[j] < k && oi[j] < bl.n_attr) {
-              const double w = (bl.mode == 1) ? 1.0 / (od[j] + 1e-12) : 1.0;
-              const Attr a = at[j];
-              ws += w;
-              c0 += w * (double)(a.rgba & 0xFFu); c1 += w * (double)((a.rgba >> 8) & 0xFFu); c2 += w * (double)((a.rgba >> 16) & 0xFFu);
-              n0 += w * (double)a.nx; n1 += w * (double)a.ny; n2 += w * (double)a.nz;
+          for (int g0 = 0; g0 < NE; g0 += GB) {
+            Attr at[GB];
+            if constexpr (GB > 1) {
+#pragma unroll
+              for (int q = 0; q < GB; ++q) {
+                const int j = g0 + q < NE ? g0 + q : NE - 1;
+                at[q] = pt_gather_attr(bl.attr, (g0 + q < NE && oi[j] != PT_NOIDX_U && rk[j] < k && oi[j] < bl.n_attr) ? oi[j] : 0u);
+              }
+            }
+            if (g0 == 0) store_results();
+#pragma unroll
+            for (int q = 0; q < GB; ++q) {
+              const int j = g0 + q < NE ? g0 + q : NE - 1;
+              if (g0 + q < NE && oi[j] != PT_NOIDX_U && rk[j] < k && oi[j] < bl.n_attr) {
+                const double w = (bl.mode == 1) ? 1.0 / (od[j] + 1e-12) : 1.0;
+                Attr a;
+                if constexpr (GB > 1) a = at[q]; else a = pt_gather_attr(bl.attr, oi[j]);
+                ws += w;
+                c0 += w * (double)(a.rgba & 0xFFu); c1 += w * (double)((a.rgba >> 8) & 0xFFu); c2 += w * (double)((a.rgba >> 16) & 0xFFu);
+                n0 += w * (double)a.nx; n1 += w * (double)a.ny; n2 += w * (double)a.nz;
+              }
             }
           }
           auto quad_sum = [](double v) { v += dpp_f64<DPP_QP_1032>(v); v += dpp_f64<DPP_QP_2301>(v); return v; };

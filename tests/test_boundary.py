@@ -130,7 +130,9 @@ def test_metric_has_no_fma_in_query_kernels():
             continue
         hier = ("knn_kernel" in name or "knn_wave_kernel" in name) and re.search(r"ELb1EEEv", name) is not None
         wave = "knn_wave_kernel" in name
-        assert int(m.group(1)) == 0 or (hier and int(m.group(1)) <= 512) or (wave and int(m.group(1)) <= 64), (name, m.group(1))
+        touches = re.search(r"\tscratch_(load|store)|\tbuffer_(load|store)_dword[^\n]*offen|\tbuffer_(load|store)_dword[^\n]*s\[0:3\]", b) is not None
+        # (a frame reserved for SGPR spills that end up in VGPR lanes shows as ScratchSize without a single scratch instruction: not traffic)
+        assert int(m.group(1)) == 0 or not touches or (hier and int(m.group(1)) <= 512) or (wave and int(m.group(1)) <= 64), (name, m.group(1))
 
 
 def test_png_writer_roundtrip(tmp_path):
