@@ -566,12 +566,17 @@ __global__ __launch_bounds__(WG) void hist_bid_kernel(const uint16_t* __restrict
     // wave-instruction.
     static_assert(TILE % 8 == 0 && (TILE + 8) <= 3 * WG * 8, "three trips cover a tile and its misalignment");
     const uint32_t a = s & ~7u;
+    uint4 v[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {                          // (the three loads first and unconditional: a group beyond the tile reads the tile's first)
+      const uint32_t g = a + ((uint32_t)j * WG + threadIdx.x) * 8u;
+      v[j] = *reinterpret_cast<const uint4*>(bid + (g < e ? g : a));
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const uint32_t g = a + ((uint32_t)j * WG + threadIdx.x) * 8u;
       if (g < e) {
-        const uint4 v = *reinterpret_cast<const uint4*>(bid + g);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const uint32_t i = g + (uint32_t)q, id = (w[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu;
