@@ -24,7 +24,7 @@ SYMBOLS = [
     "pt_resident_target_ids", "pt_resident_target_xyz", "pt_blend", "pt_blend_dev", "pt_blend_weighted", "pt_blend_weighted_dev", "pt_pca_normals",
     "pt_pca_normals_dev", "pt_merge_candidates_dev", "pt_slab_need_dev", "pt_pack_requests_dev", "pt_query_bounded_dev",
     "pt_bake_texture", "pt_texture_pad", "pt_host_alloc", "pt_host_free", "pt_upload_begin", "pt_upload_range", "pt_upload_end", "pt_stream_query",
-    "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_exchange_merge_dev", "pt_exchange_merge_local", "pt_query_exchange_blend",
+    "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_comm_abort", "pt_exchange_merge_dev", "pt_exchange_merge_local", "pt_query_exchange_blend",
 ]
 
 
@@ -113,6 +113,7 @@ def lib():
         "pt_comm_unique_id": (i32, [p]),
         "pt_comm_init": (i32, [p, i32, i32, p]),
         "pt_comm_destroy": (i32, [p]),
+        "pt_comm_abort": (i32, [p]),
         "pt_exchange_merge_dev": (i32, [p, p, i32, u64, i32, i32, p, p, p, i32, p, p, p]),
         "pt_exchange_merge_local": (i32, [p, i32, p, i32, p, i32, i32, p, p, p, i32, p, p]),
         "pt_query_exchange_blend": (i32, [p, p, i32, u64, i32, i32, p, i32, p, p, p, p, p]),

@@ -96,6 +96,9 @@ struct pt_ctx {
   DevBuf x_bounds, x_counts, x_matrix, x_off, x_req, x_row, x_rreq, x_rxyz, x_rbound, x_ans_i, x_ans_d, x_back_i, x_back_d, x_flags, x_rows;
   std::vector<uint32_t> x_send, x_recv, x_soff, x_roff;      // per peer: packets to send / to answer, and their offsets
   uint32_t* h_matrix = nullptr;                               // pinned, world * world
+  uint32_t* h_xoff = nullptr;                                 // pinned staging of the send offsets (xb_fill)
+  hipEvent_t xoff_ev = nullptr;                               // recorded behind the copy that reads h_xoff
+  bool comm_failed = false;                                   // an RCCL call failed: teardown aborts instead of waiting for peers
   // streamed upload (pt_upload_*)
   uint64_t up_n = 0;
   int up_type = -1, up_attr = 0;
@@ -782,6 +785,8 @@ void pt_ctx_destroy(pt_ctx* c) {
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);
   if (c->h_matrix) (void)hipHostFree(c->h_matrix);
+  if (c->h_xoff) (void)hipHostFree(c->h_xoff);
+  if (c->xoff_ev) (void)hipEventDestroy(c->xoff_ev);
   (void)pt_comm_destroy(c);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->sev) if (e) (void)hipEventDestroy(e);
@@ -1409,6 +1414,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;            // optional: error paths must not wait for peers
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -1416,38 +1422,50 @@ struct RcclApi {
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
-RcclApi* rccl() {          // loaded once, on first use
-  static RcclApi api;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+RcclApi* rccl() {          // loaded once, on first use (a function-local static: initialised exactly once, whatever thread comes first)
+  static const RcclApi api = [] {
+    RcclApi a;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (api.lib) break;
+      a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (a.lib) break;
     }
-    if (api.lib) {
-      auto sym = [&](const char* n) { return dlsym(api.lib, n); };
-      api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
-      api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
-      api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
-      api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
-      api.Send = (decltype(api.Send))sym("ncclSend");
-      api.Recv = (decltype(api.Recv))sym("ncclRecv");
-      api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
-      api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
-      api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
-      if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd) {
-        dlclose(api.lib);
-        api.lib = nullptr;
+    if (a.lib) {
+      auto sym = [&](const char* n) { return dlsym(a.lib, n); };
+      a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
+      a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
+      a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+      a.CommAbort = (decltype(a.CommAbort))sym("ncclCommAbort");
+      a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
+      a.Send = (decltype(a.Send))sym("ncclSend");
+      a.Recv = (decltype(a.Recv))sym("ncclRecv");
+      a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
+      a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
+      a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+      if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.Send || !a.Recv || !a.GroupStart || !a.GroupEnd) {
+        dlclose(a.lib);
+        a.lib = nullptr;
       }
     }
-  }
-  return api.lib ? &api : nullptr;
+    return a;
+  }();
+  return api.lib ? const_cast<RcclApi*>(&api) : nullptr;
+}
+// An RCCL failure poisons the communicator: mark it, so that teardown ABORTS instead of a CommDestroy that would wait for peers
+// which are themselves waiting for this rank.
+int rccl_fail(pt_ctx* c, const char* what, ncclResult_t r) {
+  c->comm_failed = true;
+  return fail(c, PT_ERR_HIP, "%s failed: %s", what, rccl()->GetErrorString ? rccl()->GetErrorString(r) : "rccl error");
 }
 #define NCCLCHK(c, call)                                                                                                      \
   do {                                                                                                                        \
     ncclResult_t r_ = (call);                                                                                                 \
-    if (r_ != ncclSuccess) return fail((c), PT_ERR_HIP, "%s failed: %s", #call, rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "rccl error"); \
+    if (r_ != ncclSuccess) return rccl_fail((c), #call, r_);                                                                  \
+  } while (0)
+// Inside ncclGroupStart .. ncclGroupEnd nothing may return: a group left open keeps every later RCCL call of this thread queued
+// (CommDestroy included) and the peers wait for the matching receives forever.  Record the first error, always close the group.
+#define NCCLGRP(first, what, call)                                                                                            \
+  do {                                                                                                                        \
+    if ((first) == ncclSuccess) { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { (first) = r_; (what) = #call; } }        \
   } while (0)
 
 struct XArgs { const void* xyz; int type; uint32_t m; int k, axis, g, me; uint32_t* idx; double* d2; };
@@ -1477,14 +1495,19 @@ int xb_fill(pt_ctx* c, const XArgs& A, const uint32_t* matrix) {
   RES(c, c->x_ans_i, std::max<size_t>(R, 1) * (size_t)A.k * 4); RES(c, c->x_ans_d, std::max<size_t>(R, 1) * (size_t)A.k * 8);
   uint32_t* off = (uint32_t*)c->x_off.p;
   uint32_t* cursor = off + 65;
-  HIPCHK(c, hipMemcpyAsync(off, c->x_soff.data(), (size_t)(g + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  // the offsets travel from PINNED memory, so the copy needs no host wait; the event says when the staging words may be rewritten
+  // (always long past: the count read-back of the next exchange sits in between -- the wait is for a caller who switched streams)
+  if (!c->h_xoff) { HIPCHK(c, hipHostMalloc((void**)&c->h_xoff, 65 * sizeof(uint32_t))); HIPCHK(c, hipEventCreateWithFlags(&c->xoff_ev, hipEventDisableTiming)); }
+  else HIPCHK(c, hipEventSynchronize(c->xoff_ev));
+  memcpy(c->h_xoff, c->x_soff.data(), (size_t)(g + 1) * sizeof(uint32_t));
+  HIPCHK(c, hipMemcpyAsync(off, c->h_xoff, (size_t)(g + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->xoff_ev, c->stream));
   HIPCHK(c, hipMemsetAsync(cursor, 0, 65 * sizeof(uint32_t), c->stream));
   if (S) {
     if (A.type == PT_F32) { const float* x = (const float*)A.xyz; pt_launch_xreq<float>(true, x, x + A.m, x + 2 * (size_t)A.m, A.d2, A.m, A.k, A.axis, (const double*)c->x_bounds.p, g, me, nullptr, off, cursor, (double*)c->x_req.p, (uint32_t*)c->x_row.p, c->stream); }
     else { const double* x = (const double*)A.xyz; pt_launch_xreq<double>(true, x, x + A.m, x + 2 * (size_t)A.m, A.d2, A.m, A.k, A.axis, (const double*)c->x_bounds.p, g, me, nullptr, off, cursor, (double*)c->x_req.p, (uint32_t*)c->x_row.p, c->stream); }
   }
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->stream));       // (x_soff is host memory the copy above reads)
   return PT_OK;
 }
 // phase c: answer the requests received (x_rreq, x_roff[g] of them) with a radius-bounded search of this rank's slab
@@ -1558,8 +1581,19 @@ int pt_comm_init(pt_ctx* c, int world, int rank, const void* id) {
 
 int pt_comm_destroy(pt_ctx* c) {
   if (!c) return PT_ERR_ARG;
+  if (c->comm_failed) return pt_comm_abort(c);
   if (c->nccl_comm && rccl()) { (void)hipSetDevice(c->device); (void)rccl()->CommDestroy((ncclComm_t)c->nccl_comm); }
   c->nccl_comm = nullptr; c->world = 1; c->rank = 0;
+  return PT_OK;
+}
+
+int pt_comm_abort(pt_ctx* c) {
+  if (!c) return PT_ERR_ARG;
+  if (c->nccl_comm && rccl()) {
+    (void)hipSetDevice(c->device);
+    if (rccl()->CommAbort) (void)rccl()->CommAbort((ncclComm_t)c->nccl_comm);     // without ncclCommAbort the communicator is leaked: never wait here
+  }
+  c->nccl_comm = nullptr; c->world = 1; c->rank = 0; c->comm_failed = false;
   return PT_OK;
 }
 
@@ -1582,33 +1616,37 @@ int pt_exchange_merge_dev(pt_ctx* c, const void* tgt_xyz_dev, int xyz_type, uint
     RES(c, c->x_matrix, 64 * 64 * sizeof(uint32_t));
     NCCLCHK(c, rccl()->AllGather(c->x_counts.p, c->x_matrix.p, 64, ncclUint32, comm, c->stream));      // rows of 64 counters, g of them
     HIPCHK(c, hipMemcpyAsync(c->h_matrix, c->x_matrix.p, (size_t)g * 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));         // the one host read-back: every later size follows from the matrix
+    HIPCHK(c, hipStreamSynchronize(c->stream));         // the exchange's ONE host wait: every later size follows from the matrix
     std::vector<uint32_t> matrix((size_t)g * g);
     for (int r = 0; r < g; ++r) for (int s2 = 0; s2 < g; ++s2) matrix[(size_t)r * g + s2] = c->h_matrix[(size_t)r * 64 + s2];
     { int r = xb_fill(c, A, matrix.data()); if (r) return r; }
+    ncclResult_t gerr = ncclSuccess;
+    const char* gwhat = "";
     NCCLCHK(c, rccl()->GroupStart());
     for (int p = 0; p < g; ++p) {
       if (p == me) continue;
-      if (c->x_send[(size_t)p]) NCCLCHK(c, rccl()->Send((const double*)c->x_req.p + (size_t)c->x_soff[(size_t)p] * 4, (size_t)c->x_send[(size_t)p] * 4, ncclFloat64, p, comm, c->stream));
-      if (c->x_recv[(size_t)p]) NCCLCHK(c, rccl()->Recv((double*)c->x_rreq.p + (size_t)c->x_roff[(size_t)p] * 4, (size_t)c->x_recv[(size_t)p] * 4, ncclFloat64, p, comm, c->stream));
+      if (c->x_send[(size_t)p]) NCCLGRP(gerr, gwhat, rccl()->Send((const double*)c->x_req.p + (size_t)c->x_soff[(size_t)p] * 4, (size_t)c->x_send[(size_t)p] * 4, ncclFloat64, p, comm, c->stream));
+      if (c->x_recv[(size_t)p]) NCCLGRP(gerr, gwhat, rccl()->Recv((double*)c->x_rreq.p + (size_t)c->x_roff[(size_t)p] * 4, (size_t)c->x_recv[(size_t)p] * 4, ncclFloat64, p, comm, c->stream));
     }
-    NCCLCHK(c, rccl()->GroupEnd());
+    NCCLGRP(gerr, gwhat, rccl()->GroupEnd());
+    if (gerr != ncclSuccess) { if (gwhat[0] && !strstr(gwhat, "GroupEnd")) (void)rccl()->GroupEnd(); return rccl_fail(c, gwhat, gerr); }
     { int r = xc_answer(c, A); if (r) return r; }
     NCCLCHK(c, rccl()->GroupStart());
     for (int p = 0; p < g; ++p) {
       if (p == me) continue;
       const size_t ro = (size_t)c->x_roff[(size_t)p] * k, rc = (size_t)c->x_recv[(size_t)p] * k, so = (size_t)c->x_soff[(size_t)p] * k, sc = (size_t)c->x_send[(size_t)p] * k;
-      if (rc) { NCCLCHK(c, rccl()->Send((const uint32_t*)c->x_ans_i.p + ro, rc, ncclUint32, p, comm, c->stream)); NCCLCHK(c, rccl()->Send((const double*)c->x_ans_d.p + ro, rc, ncclFloat64, p, comm, c->stream)); }
-      if (sc) { NCCLCHK(c, rccl()->Recv((uint32_t*)c->x_back_i.p + so, sc, ncclUint32, p, comm, c->stream)); NCCLCHK(c, rccl()->Recv((double*)c->x_back_d.p + so, sc, ncclFloat64, p, comm, c->stream)); }
+      if (rc) { NCCLGRP(gerr, gwhat, rccl()->Send((const uint32_t*)c->x_ans_i.p + ro, rc, ncclUint32, p, comm, c->stream)); NCCLGRP(gerr, gwhat, rccl()->Send((const double*)c->x_ans_d.p + ro, rc, ncclFloat64, p, comm, c->stream)); }
+      if (sc) { NCCLGRP(gerr, gwhat, rccl()->Recv((uint32_t*)c->x_back_i.p + so, sc, ncclUint32, p, comm, c->stream)); NCCLGRP(gerr, gwhat, rccl()->Recv((double*)c->x_back_d.p + so, sc, ncclFloat64, p, comm, c->stream)); }
     }
-    NCCLCHK(c, rccl()->GroupEnd());
+    NCCLGRP(gerr, gwhat, rccl()->GroupEnd());
+    if (gerr != ncclSuccess) { if (gwhat[0] && !strstr(gwhat, "GroupEnd")) (void)rccl()->GroupEnd(); return rccl_fail(c, gwhat, gerr); }
     { int r = xd_merge(c, A, blend_mode, rgb_dev, nrm_dev); if (r) return r; }
     HIPCHK(c, hipEventRecord(c->xev[1], c->stream));
     return PT_OK;
   };
   const int r = body();
   c->sync = sync_save;
-  if (r != PT_OK) return r;
+  if (r != PT_OK) { c->comm_failed = true; return r; }      // whatever failed, the peers may be left waiting: teardown must abort, not wait
   if (st) {
     const uint64_t S = c->x_soff[(size_t)g], R = c->x_roff[(size_t)g];
     st->crossing = S; st->answered = R;

@@ -14,12 +14,14 @@
 // stdout keeps the reference's lines and order: rank 0 prints the read / build / search lines, finalize the draw / output lines,
 // the launcher the totals.
 #pragma once
+#include <signal.h>
 #include <spawn.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -91,7 +93,8 @@ inline int run_rank(const Options& o) {
   int dev = o.device + rank;
   int rc = pt_ctx_create(&ctx, &dev, 1);                       // the process's first GPU call
   if (rc != PT_OK) { std::cerr << "pointsTransfer[rank " << rank << "]: no usable HIP device " << dev << " (pt_ctx_create returned " << rc << ")" << std::endl; return 1; }
-  auto die = [&](const char* what) { std::cerr << "pointsTransfer[rank " << rank << "]: " << what << ": " << pt_last_error(ctx) << std::endl; pt_ctx_destroy(ctx); return 1; };
+  // error exits ABORT the communicator (pt_comm_abort: ncclCommAbort): a CommDestroy could wait for peers that wait for this rank
+  auto die = [&](const char* what) { std::cerr << "pointsTransfer[rank " << rank << "]: " << what << ": " << pt_last_error(ctx) << std::endl; pt_comm_abort(ctx); pt_ctx_destroy(ctx); return 1; };
   {   // communicator: rank 0 creates the id, everybody reads it from the rendezvous directory
     unsigned char id[PT_COMM_ID_BYTES];
     const std::string idf = o.rendezvous + "/rccl_id";
@@ -125,7 +128,7 @@ inline int run_rank(const Options& o) {
   const bool opened = ply::read_cloud_soa(o.cloud, cloud, declared, [&](size_t b) { void* q = std::malloc(b ? b : 1); if (q) mem.push_back(q); return q; },
                                           [](uint64_t) { return true; }, [](uint64_t, uint64_t) {}, o.ply_threads);
   auto free_mem = [&]() { for (void* q : mem) std::free(q); mem.clear(); };
-  if (!opened) { if (rank == 0) std::cerr << "Cannot read or find point cloud file: " << o.cloud << std::endl; free_mem(); pt_ctx_destroy(ctx); return 3; }
+  if (!opened) { if (rank == 0) std::cerr << "Cannot read or find point cloud file: " << o.cloud << std::endl; free_mem(); pt_comm_abort(ctx); pt_ctx_destroy(ctx); return 3; }
   if (rank == 0) {
     std::cout << "PC Point count: " << declared << std::endl;
     std::cout << "Read point set in: " << since(t_task) << " seconds" << std::endl;
@@ -147,7 +150,7 @@ inline int run_rank(const Options& o) {
   t_task = clk::now();
   // ---- mesh: the vertices homed in this slab ---------------------------------------------------------------------------------
   ply::FastMesh mesh;
-  if (!ply::read_mesh_any(o.mesh, mesh, o.ply_threads)) { if (rank == 0) std::cerr << "Cannot read or find mesh file: " << o.mesh << std::endl; free_mem(); pt_ctx_destroy(ctx); return 3; }
+  if (!ply::read_mesh_any(o.mesh, mesh, o.ply_threads)) { if (rank == 0) std::cerr << "Cannot read or find mesh file: " << o.mesh << std::endl; free_mem(); pt_comm_abort(ctx); pt_ctx_destroy(ctx); return 3; }
   if (rank == 0) {
     std::cout << "Mesh vertex count: " << mesh.vertex_count << std::endl;
     std::cout << "Mesh face count: " << mesh.face_count << std::endl;
@@ -253,23 +256,45 @@ inline int run_finalize(const Options& o, WritePly&& write_ply) {
   return 0;
 }
 
-// the launcher: fresh child processes only (this process never initialises HIP)
-inline int spawn_and_wait(const std::vector<std::vector<std::string>>& cmds) {
+// the launcher: fresh child processes only (this process never initialises HIP).  Children are reaped in the order they END; the
+// first one that fails (non-zero exit, a signal) takes the others down -- its peers would otherwise wait for it inside an RCCL
+// collective for ever, and the launcher with them: SIGTERM, a grace period, SIGKILL, all of them reaped before returning.
+inline int spawn_and_wait(const std::vector<std::vector<std::string>>& cmds, double grace_s = 5.0) {
   std::vector<pid_t> pids;
+  int worst = 0;
   for (const auto& cmd : cmds) {
     std::vector<char*> argv;
     for (const std::string& a : cmd) argv.push_back(const_cast<char*>(a.c_str()));
     argv.push_back(nullptr);
     pid_t pid = 0;
-    if (posix_spawn(&pid, argv[0], nullptr, nullptr, argv.data(), environ) != 0) { std::cerr << "pointsTransfer: cannot start " << argv[0] << std::endl; return 1; }
+    if (posix_spawn(&pid, argv[0], nullptr, nullptr, argv.data(), environ) != 0) { std::cerr << "pointsTransfer: cannot start " << argv[0] << std::endl; worst = 1; break; }
     pids.push_back(pid);
   }
-  int worst = 0;
-  for (pid_t pid : pids) {
+  size_t live = pids.size();
+  auto reap = [&](pid_t pid, int st) {
+    for (pid_t& q : pids) if (q == pid) { q = -1; --live; }
+    const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+    if (rc != 0 && worst == 0) worst = rc;                              // the FIRST failure is the one reported (the rest are its victims)
+  };
+  while (live && worst == 0) {
     int st = 0;
-    if (waitpid(pid, &st, 0) < 0) worst = std::max(worst, 1);
-    else if (WIFEXITED(st)) worst = std::max(worst, WEXITSTATUS(st));
-    else worst = std::max(worst, 1);
+    const pid_t pid = waitpid(-1, &st, 0);
+    if (pid < 0) { if (errno == EINTR) continue; worst = 1; break; }
+    reap(pid, st);
+  }
+  if (live) {                                                            // somebody failed: nobody else may be left waiting for it
+    std::cerr << "pointsTransfer: a process of the job failed (exit " << worst << "): stopping the other " << live << std::endl;
+    for (pid_t q : pids) if (q > 0) kill(q, SIGTERM);
+    const auto t0 = clk::now();
+    bool killed = false;
+    while (live) {
+      int st = 0;
+      const pid_t pid = waitpid(-1, &st, WNOHANG);
+      if (pid > 0) { const int keep = worst; reap(pid, st); worst = keep; continue; }
+      if (pid < 0 && errno != EINTR) break;
+      if (!killed && since(t0) > grace_s) { for (pid_t q : pids) if (q > 0) kill(q, SIGKILL); killed = true; }
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    }
   }
   return worst;
 }
@@ -278,6 +303,7 @@ inline int run_launcher(const Options& o, const std::string& self, const std::ve
   char tmpl[] = "/tmp/pointsTransfer.XXXXXX";
   if (!mkdtemp(tmpl)) { std::cerr << "pointsTransfer: cannot create a rendezvous directory" << std::endl; return 1; }
   const std::string dir = tmpl;
+  std::cerr << "[pt_hip launcher] rendezvous " << dir << std::endl;
   auto cmd_for = [&](const std::vector<std::string>& extra) {
     std::vector<std::string> c = {self, o.cloud, o.mesh};
     c.insert(c.end(), passthrough.begin(), passthrough.end());

@@ -257,15 +257,21 @@ class PointsTransfer:
     def comm_destroy(self):
         self._chk(self._L.pt_comm_destroy(self._h))
 
-    def exchange_merge_dev(self, xyz_dev, xyz_type, m, k, axis, bounds, idx_dev, d2_dev, blend_mode=-1, rgb_dev=None, nrm_dev=None):
+    def comm_abort(self):
+        """Error-path teardown (ncclCommAbort): never waits for peers."""
+        self._chk(self._L.pt_comm_abort(self._h))
+
+    def exchange_merge_dev(self, xyz_dev, xyz_type, m, k, axis, bounds, idx_dev, d2_dev, blend_mode=-1, rgb_dev=None, nrm_dev=None, want_stats=True):
         """Complete the home-slab lists idx_dev / d2_dev ([m, k], in place) with the other ranks' candidates over RCCL; returns
-        the exchange counters.  blend_mode >= 0 redoes the blend of the completed rows into rgb_dev / nrm_dev."""
+        the exchange counters.  blend_mode >= 0 redoes the blend of the completed rows into rgb_dev / nrm_dev.
+        want_stats=False passes no stats struct: the call then only enqueues after its one count read-back (no trailing host wait)
+        and returns {}."""
         self._adopt_torch_stream()
         b = (C.c_double * len(bounds))(*bounds)
-        st = capi.ExchangeStats()
+        st = capi.ExchangeStats() if want_stats else None
         self._chk(self._L.pt_exchange_merge_dev(self._h, _ptr(xyz_dev), xyz_type, m, k, axis, b, _ptr(idx_dev), _ptr(d2_dev), blend_mode,
-                                                _ptr(rgb_dev), _ptr(nrm_dev), C.byref(st)))
-        return {f[0]: getattr(st, f[0]) for f in st._fields_}
+                                                _ptr(rgb_dev), _ptr(nrm_dev), C.byref(st) if want_stats else None))
+        return {f[0]: getattr(st, f[0]) for f in st._fields_} if want_stats else {}
 
     @staticmethod
     def exchange_merge_local(pts, xyz_devs, xyz_type, k, axis, bounds, idx_devs, d2_devs, blend_mode=-1, rgb_devs=None, nrm_devs=None):

@@ -8,9 +8,14 @@ Default workload = BASELINE config 4, the one north_star quotes the target on: 1
 k=8, uniform fp32, seed 0xC4 (fits one MI355X: ~63 GB).  With --gpus N the same cloud is sharded by spatial
 slab over N ranks (strong scaling: total work fixed), one process per GPU, RCCL via torch.distributed.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C4] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C4|C5] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) the process becomes a LAUNCHER: before torch is imported or
+any GPU call made it starts N fresh rank processes of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT),
+relays rank 0's JSON line, stops every rank as soon as one fails, and exits with the first failure's code.  Under
+torch.distributed.run the ranks are the launcher's and this file only reads the environment.
 
 Prints ONE JSON line on rank 0 (contract fields + "roofline" + "cpu_baseline" + per-phase detail).
 """
@@ -127,6 +132,83 @@ def cpu_baseline(n_total, m_total, k, seed):
     }
 
 
+def dry_run(args, world, rank, dist, torch):
+    """--dry-run: everything of a multi-rank run EXCEPT the GPU work -- rendezvous, the fence, K "steps" (a sleep), the max over ranks,
+    one JSON line from rank 0 -- so that the launcher and the collectives' plumbing are testable on a machine without GPUs."""
+    if world > 1:
+        dist.init_process_group(args.backend if args.backend == "gloo" else "gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "metric": "none (launcher / rendezvous rehearsal, no GPU work)", "value": None, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def launch_ranks(n, argv):
+    """The launcher of a plain `bench.py --gpus N`: N fresh children (never an exec, never a fork of a process that touched the
+    GPU -- this one has not even imported torch), rank 0's stdout relayed, everybody else's sent to stderr so that stdout carries
+    ONE JSON line; the first rank that fails takes the others down (they would wait for it in a collective) and its exit code is
+    the launcher's."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as so:                      # a free rendezvous port on the loop-back interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+
+    def relay():                                     # rank 0's JSON line(s) to stdout, anything else it prints (library banners) to stderr
+        for raw in procs[0].stdout:
+            line = raw.decode(errors="replace")
+            out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+            out.write(line)
+            out.flush()
+    import threading
+    pump = threading.Thread(target=relay, daemon=True)
+    pump.start()
+    worst, live = 0, set(range(n))
+    try:
+        while live and not worst:
+            for r in sorted(live):
+                rc = procs[r].poll()
+                if rc is not None:
+                    live.discard(r)
+                    if rc and not worst:
+                        worst = rc if rc > 0 else 128 - rc
+                        print("bench.py: rank %d exited with code %d: stopping the other %d rank(s)" % (r, rc, len(live)), file=sys.stderr)
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        worst = 130
+    if live:
+        for r in live:
+            procs[r].send_signal(signal.SIGTERM)
+        t0 = time.time()
+        for r in sorted(live):
+            try:
+                procs[r].wait(timeout=max(0.1, 10.0 - (time.time() - t0)))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    pump.join(timeout=5)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,25 +219,40 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: ranks may share one GPU, collectives staged through host memory")
     ap.add_argument("--exchange", default="native", choices=["native", "torch"],
-                    help="N > 1: native = pt_exchange_merge_dev (RCCL behind the C ABI: one count-matrix all-gather, grouped send/recv); "
-                         "torch = the torch.distributed all-gather protocol of sharding.py (what the gloo CPU tests drive)")
+                    help="N > 1: native = pt_exchange_merge_dev (RCCL behind the C ABI: one count-matrix all-gather, grouped send/recv) -- if its "
+                         "communicator does not come up the run FAILS (non-zero exit), it never changes protocol by itself; "
+                         "torch = the torch.distributed all-gather protocol of sharding.py (what the gloo CPU tests drive), an explicit choice")
     ap.add_argument("--source-points", dest="n", type=int, default=0, help="override the workload's source count (rehearsals)")
     ap.add_argument("--target-points", dest="m", type=int, default=0, help="override the workload's target count (rehearsals)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch + rendezvous + fence + max-over-ranks timing only, no GPU work: what the CPU suite drives (gloo). The JSON "
+                         "line says dry_run and carries no value")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="rehearsal of a failing rank: that rank exits with code 9 before the rendezvous")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world == 0:
+        if args.gpus > 1:           # plain start: become the launcher -- decided before torch is imported or any GPU call is made
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        world = 1
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d" % (args.gpus, world))
+    if rank == args.fail_rank:
+        sys.exit(9)
 
     import torch
     import torch.distributed as dist
+    if args.dry_run:
+        return dry_run(args, world, rank, dist, torch)
+    # device_count() does not initialise the GPU on this image: refuse BEFORE any rank enters a collective the others would wait in
+    if args.backend == "nccl" and torch.cuda.device_count() < world:
+        sys.exit("bench.py: --gpus %d needs %d visible GPUs, this machine shows %d" % (world, world, torch.cuda.device_count()))
     import __graft_entry__ as g
     pkg = g.load_package()
     from pt_amd import sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     if args.backend == "gloo":
         local_rank = local_rank % torch.cuda.device_count()
@@ -180,6 +277,26 @@ def main():
     axis = 0
     bounds = sharding.uniform_slab_bounds(world)
     pt = pkg.PointsTransfer(device=local_rank, k_hint=k)
+    native = world > 1 and args.exchange == "native"
+    if native and args.backend != "nccl":
+        sys.exit("bench.py: --exchange native needs --backend nccl (RCCL places one rank per GPU); the gloo rehearsal takes --exchange torch")
+    if native:
+        # The library's own RCCL communicator, joined BEFORE the heavy GPU work (include/pt_api.h); rank 0 creates the id and
+        # torch.distributed only carries its 128 bytes.  Any failure here ends the rank with a non-zero code -- the launcher then stops
+        # the others, which may already be inside the collective ncclCommInitRank -- and NEVER switches to another protocol: a run that
+        # was asked for the native exchange measures the native exchange or nothing.
+        try:
+            uid = [pt.comm_unique_id() if rank == 0 else None]
+        except Exception as e:                      # noqa: BLE001
+            print("bench.py: rank %d: pt_comm_unique_id failed (%s): is librccl loadable?" % (rank, e), file=sys.stderr)
+            uid = [None]
+        dist.broadcast_object_list(uid, src=0, device=dev)
+        if uid[0] is None:
+            sys.exit("bench.py: rank %d: no RCCL id from rank 0 -- the native exchange cannot start (use --exchange torch to measure the other protocol)" % rank)
+        try:
+            pt.comm_init(world, rank, uid[0])
+        except Exception as e:                      # noqa: BLE001
+            sys.exit("bench.py: rank %d: pt_comm_init failed (%s)" % (rank, e))
     dist_name, type_name = WORKLOAD_KIND.get(args.workload, ("uniform", "f32"))
     gen = dict(dist=pkg.capi.DIST_CLUSTERED if dist_name == "clustered" else pkg.capi.DIST_UNIFORM,
                xyz_type=pkg.F16 if type_name == "f16" else pkg.F32)
@@ -198,33 +315,6 @@ def main():
     else:
         pt.build_synth(n_total, seed, **gen)
         pt.targets_synth(m_total, seed, **gen)
-    native = world > 1 and args.exchange == "native" and args.backend == "nccl"
-    if native:        # the library's own RCCL communicator: rank 0 creates the id, torch.distributed only carries its 128 bytes
-        # Every rank must end up on the same protocol: if the communicator does not come up on ANY rank (librccl not loadable, an RCCL
-        # error), all of them fall back to the torch.distributed exchange -- said on stderr and in the JSON line's config.exchange.
-        ok = 1
-        try:
-            uid = [pt.comm_unique_id() if rank == 0 else None]
-        except Exception as e:                      # noqa: BLE001 -- whatever it is, the other ranks must not be left waiting
-            uid, ok = [None], 0
-            print("bench.py: rank %d: pt_comm_unique_id failed (%s)" % (rank, e), file=sys.stderr)
-        dist.broadcast_object_list(uid, src=0, device=dev)
-        if uid[0] is None:
-            ok = 0
-        else:
-            try:
-                pt.comm_init(world, rank, uid[0])
-            except Exception as e:                  # noqa: BLE001
-                ok = 0
-                print("bench.py: rank %d: pt_comm_init failed (%s)" % (rank, e), file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if ok:
-                pt.comm_destroy()
-            native = False
-            if rank == 0:
-                print("bench.py: native RCCL exchange unavailable on at least one rank: falling back to --exchange torch", file=sys.stderr)
     n_loc, m_loc = pt.num_source, pt.num_targets
     idx = torch.empty((m_loc, k), dtype=torch.int32, device=dev)
     d2 = torch.empty((m_loc, k), dtype=torch.float64, device=dev)
@@ -257,7 +347,7 @@ def main():
         if world > 1 and record:                   # (the exchange synchronises with the host anyway: its wall time is a fair phase time)
             torch.cuda.synchronize(); tx = time.perf_counter()
         if native:         # count matrix -> owner-to-owner requests -> bounded answers -> merge -> re-blend, all behind the C ABI
-            xs = pt.exchange_merge_dev(xyz, pkg.F32, m_loc, k, axis, bounds, idx, d2, pkg.BLEND_MEAN, rgb, nrm)
+            xs = pt.exchange_merge_dev(xyz, pkg.F32, m_loc, k, axis, bounds, idx, d2, pkg.BLEND_MEAN, rgb, nrm, want_stats=record)
         else:
             xs = sharding.exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds, on_changed=reblend)
         if world > 1 and record:
@@ -314,7 +404,7 @@ def main():
                        "step": "grid build + target binning + k-NN with fused mean blend + slab exchange/merge%s, inputs resident in HBM"
                                % (" + PCA normals" if with_pca else ""),
                        "parallelism": "slab%d" % world if world > 1 else "single", "backend": args.backend if world > 1 else None,
-                       "exchange": ("native RCCL (pt_exchange_merge_dev)" if native else "torch.distributed all-gather") if world > 1 else None},
+                       "exchange": ("native RCCL (pt_exchange_merge_dev)" if native else "torch.distributed all-gather (--exchange torch)") if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(KERNEL_NAMES[dom], args.workload, world),
                          "traffic_source": pmc_file, "alg_bytes_per_launch": alg, "alg_bytes_formula": "SURVEY.md 8(d)",

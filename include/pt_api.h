@@ -221,7 +221,7 @@ int  pt_query_bounded_dev(pt_ctx*, const void* xyz_dev, int xyz_type, const doub
 /* ---- native slab exchange: RCCL over xGMI behind the C ABI, one rank per process and GPU ---------------
  * After every rank has searched its HOME targets in its own slab (pt_query_*), pt_exchange_merge_dev completes the lists:
  *   1. the targets whose k-th distance reaches another slab (Distance::min_distance_to_rectangle, src/Distance.h:27-57, on
- *      the slab boxes) are counted per destination; ONE all-gather ships the G x G count matrix (the only host read-back);
+ *      the slab boxes) are counted per destination; ONE all-gather ships the G x G count matrix (its read-back is the exchange's only host wait);
  *   2. grouped ncclSend / ncclRecv carry 32-byte request packets {x, y, z, k-th d2} owner to owner (all links at once);
  *   3. every rank answers what it received with a radius-bounded search of its slab;
  *   4. the k candidates per request travel back the same way and are merged under the total order (d2, index);
@@ -241,6 +241,10 @@ typedef struct pt_exchange_stats_t {
 int  pt_comm_unique_id(void* id_out);
 int  pt_comm_init(pt_ctx*, int world, int rank, const void* id);
 int  pt_comm_destroy(pt_ctx*);
+/* Error-path teardown: ncclCommAbort instead of ncclCommDestroy -- never waits for peers (which may be waiting for this rank).
+ * pt_comm_destroy and pt_ctx_destroy take this path by themselves once an RCCL call or any phase of an exchange has failed on
+ * the context; a host that gives up for reasons of its own (a failed build, a bad input file) calls it before exiting. */
+int  pt_comm_abort(pt_ctx*);
 int  pt_exchange_merge_dev(pt_ctx*, const void* tgt_xyz_dev, int xyz_type, uint64_t m, int k, int slab_axis, const double* slab_bounds,
                            uint32_t* idx_dev, double* d2_dev, int blend_mode, float* rgb_dev, float* nrm_dev, pt_exchange_stats_t* stats_or_null);
 /* One rank's whole query for a C++ host that holds no device memory: the home targets (planar host xyz) are searched in this
@@ -276,7 +280,8 @@ int   pt_upload_end(pt_ctx*);
  * of the chunk are merged into the running k best under the same total order (d2, index).  Indices are 64-bit -- a streamed
  * cloud may hold more than 2^32 points -- and are `first_id` + the point's position in `xyz`.  The result is bit-identical to
  * a resident search of the whole cloud.  xyz: planar, n points of xyz_type (PT_F32 / PT_F64; the targets' type);
- * idx64_out / d2_out: host, [m][k].  The context's resident cloud is replaced (by the last chunk). */
+ * idx64_out / d2_out: host, [m][k].  Afterwards NO source cloud is resident in the context (the chunks lived in the stage
+ * buffers): a later pt_query_* needs a pt_build_* first and fails with PT_ERR_STATE otherwise. */
 int  pt_stream_query(pt_ctx*, const void* xyz, int xyz_type, uint64_t n, uint64_t chunk_points, uint64_t first_id, int k,
                      uint64_t* idx64_out, double* d2_out);
 

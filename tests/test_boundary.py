@@ -169,3 +169,99 @@ def test_png_writer_roundtrip(tmp_path):
         raw = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8).reshape(h, w * 4 + 1)
         assert (raw[:, 0] == 0).all()
         assert np.array_equal(raw[:, 1:].reshape(h, w, 4)[:, :, [2, 1, 0, 3]], want)
+
+
+# ---- multi-process launchers without a GPU ("start, fail loudly, be testable") -------------------------------
+def test_cli_launcher_stops_the_job_when_a_rank_fails():
+    """host/sharded.h::spawn_and_wait -- the launcher of `pointsTransfer --gpus N`: children reaped as they end, the first failure
+    SIGTERMs (then SIGKILLs) the others and is the exit code; a peer that would wait ten minutes is gone within seconds."""
+    exe = os.path.join(PKG, "launcher_selftest")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "launcher selftest ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_cli_sharded_launch_fails_fast_without_devices(tmp_path):
+    """`pointsTransfer cloud mesh --gpus 2` where no rank can open its device (this container has no GPU; on a GPU box device 99
+    does not exist): non-zero exit within seconds, no rank left behind, the rendezvous directory removed."""
+    exe = os.path.join(PKG, "pointsTransfer")
+    (tmp_path / "c.ply").write_text("ply\nformat ascii 1.0\nelement vertex 1\nend_header\n0 0 0 0 0 1 1 2 3\n")
+    (tmp_path / "m.ply").write_text("ply\nformat ascii 1.0\nelement vertex 0\nelement face 0\nend_header\n")
+    r = subprocess.run([exe, str(tmp_path / "c.ply"), str(tmp_path / "m.ply"), "--gpus", "2", "--device", "99"], capture_output=True, text=True,
+                       cwd=tmp_path, timeout=60)
+    assert r.returncode != 0 and "no usable HIP device" in r.stderr
+    dirs = [l.split()[-1] for l in r.stderr.splitlines() if l.startswith("[pt_hip launcher] rendezvous")]
+    assert dirs and not os.path.exists(dirs[0])
+
+
+def _bench(*argv, timeout=180):
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the process becomes the launcher (before torch is imported), starts two fresh
+    ranks, and stdout carries exactly one JSON line.  --dry-run: rendezvous, fence and max-over-ranks over gloo, no GPU work."""
+    import json
+    r = _bench("--gpus", "2", "--dry-run", "--backend", "gloo", "--steps", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["value"] is None
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    """A rank that dies before the rendezvous: the others sit in init_process_group waiting for it -- the launcher stops them and
+    exits with the failed rank's code, promptly."""
+    import time
+    t0 = time.time()
+    r = _bench("--gpus", "3", "--dry-run", "--backend", "gloo", "--fail-rank", "2")
+    assert r.returncode == 9 and time.time() - t0 < 120, r.stderr[-2000:]
+    assert "stopping the other" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """--gpus N beyond the visible devices: every rank refuses before entering a collective; non-zero exit with that sentence.
+    (No GPU in the CPU container: N = 2 is already too many.  On a GPU box this test asks for one more than there are.)"""
+    import torch
+    n = torch.cuda.device_count() + 1
+    if n < 2:
+        n = 2
+    r = _bench("--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert r.returncode != 0 and "visible GPUs" in r.stderr and not r.stdout.strip()
+
+
+def test_python_sources_are_import_clean():
+    """Every Python file compiles and uses no undefined names (a NameError in a test that only ever SKIPS is found here, not on the
+    first multi-GPU box): py_compile + a symbol-table pass over module- and function-level names."""
+    import ast
+    import builtins
+    import py_compile
+    import symtable
+    files = []
+    for base in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools"), PKG, os.path.join(ROOT, "oracle")):
+        files += [os.path.join(base, f) for f in sorted(os.listdir(base)) if f.endswith(".py")]
+    assert len(files) > 20
+    bad = []
+    for path in files:
+        py_compile.compile(path, doraise=True)
+        src = open(path).read()
+        top = symtable.symtable(src, path, "exec")
+        module_names = {s.get_name() for s in top.get_symbols() if s.is_assigned() or s.is_imported() or s.is_namespace()} | set(dir(builtins)) | {"__file__", "__name__", "__doc__"}
+        star = any(isinstance(n, ast.ImportFrom) and any(a.name == "*" for a in n.names) for n in ast.walk(ast.parse(src)))
+
+        def walk(tab, enclosing):
+            local = {s.get_name() for s in tab.get_symbols() if s.is_assigned() or s.is_imported() or s.is_parameter() or s.is_namespace()}
+            if tab.get_type() != "class":
+                enclosing = enclosing | local
+            for sym in tab.get_symbols():
+                n = sym.get_name()
+                if sym.is_referenced() and not (n in local or n in enclosing or n in module_names or sym.is_free()):
+                    if sym.is_global() and not star:
+                        bad.append("%s: %s (in %s)" % (os.path.relpath(path, ROOT), n, tab.get_name()))
+            for ch in tab.get_children():
+                walk(ch, enclosing)
+        walk(top, set())
+    assert not bad, "undefined names: " + "; ".join(bad)

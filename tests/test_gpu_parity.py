@@ -1,6 +1,9 @@
 """GPU suite: the HIP path, called through the C ABI, against the CPU oracle and the golden fixtures.
 Bar: neighbour indices and squared distances bit-exact; blended attributes within 1e-5 (colour/255, normals)."""
 import math
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -1118,7 +1121,7 @@ def test_rccl_communicator_world_of_one(pkg, oracle):
 
 def test_native_exchange_two_ranks_over_rccl(pkg, oracle, tmp_path):
     """World size 2 over RCCL proper: needs two visible GPUs (one rank per GPU; RCCL refuses two ranks on one device)."""
-    import subprocess, sys, torch
+    import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs: this box shows %d (RCCL cannot place two ranks on one device)" % torch.cuda.device_count())
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_worker.py")
@@ -1133,7 +1136,7 @@ def test_cli_sharded_path(tmp_path, pkg, oracle, gpus):
     """pointsTransfer ... --gpus N: launcher -> one rank process per GPU (RCCL communicator, slab build with global indices, home
     search, native exchange) -> finalize (bake on the referenced points only).  texture.png must equal the single-process run's
     byte for byte after decoding; --gpus 1 runs everywhere, --gpus 2 needs two GPUs."""
-    import os, subprocess, torch
+    import torch
     if gpus > torch.cuda.device_count():
         pytest.skip("needs %d GPUs: this box shows %d" % (gpus, torch.cuda.device_count()))
     from _bake_cases import make_case
@@ -1152,7 +1155,9 @@ def test_cli_sharded_path(tmp_path, pkg, oracle, gpus):
     rows = lambda d: np.array([[float(v) for v in l.split()] for l in open(d / "transfer.ply").read().split("end_header\n")[1].strip().splitlines()[:verts.shape[1]]])
     a, b = rows(d1), rows(d2_)
     assert np.abs(a[:, 8:] - b[:, 8:]).max() <= 1 and np.abs(a[:, :8] - b[:, :8]).max() <= 2e-5
-    assert not [f for f in os.listdir("/tmp") if f.startswith("pointsTransfer.") and os.path.isdir(os.path.join("/tmp", f)) and os.stat(os.path.join("/tmp", f)).st_uid == os.getuid() and not os.listdir(os.path.join("/tmp", f))] or True
+    # the launcher removes its rendezvous directory: none of THIS run's may be left (named in its stderr line, see run_launcher)
+    left = [l.split()[-1] for l in r2.stderr.splitlines() if l.startswith("[pt_hip launcher] rendezvous")]
+    assert left and not any(os.path.exists(d) for d in left)
 
 
 # ---- refined cells (pt_refine.hip): sub-grids inside heavy cells, descended into by the group kernel ---------------------------
