@@ -904,6 +904,30 @@ int pt_set_attributes(pt_ctx* c, const uint8_t* rgb, const float* nrm, uint64_t 
   return finish(c);
 }
 
+int pt_set_attributes_range(pt_ctx* c, uint64_t first, uint64_t count, const uint8_t* rgb, const float* nrm, uint64_t n_total) {
+  if (!c) return PT_ERR_ARG;
+  { int r = check_n(c, n_total, "n_total"); if (r) return r; }
+  if (first > n_total || count > n_total - first) return fail(c, PT_ERR_ARG, "pt_set_attributes_range: [first, first + count) outside the table of n_total records");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->has_attr || c->n_total != n_total || c->attr.cap < std::max<uint64_t>(n_total, 1) * sizeof(Attr)) {
+    RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
+    HIPCHK(c, hipMemsetAsync(c->attr.p, 0, std::max<uint64_t>(n_total, 1) * sizeof(Attr), c->stream));       // ranges never written read as black / zero normal
+  }
+  if (count) {
+    RES(c, c->misc, count * 15);
+    uint8_t* base = (uint8_t*)c->misc.p;
+    const uint8_t* drgb = nullptr;
+    const float* dnrm = nullptr;
+    if (nrm) { int r = copy_in(c, base, nrm, count * 12, 0); if (r) return r; dnrm = (const float*)base; }
+    if (rgb) { int r = copy_in(c, base + count * 12, rgb, count * 3, 0); if (r) return r; drgb = base + count * 12; }
+    pt_launch_pack_attr(drgb, dnrm, (uint32_t)count, (Attr*)c->attr.p + first, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));              // the staging buffer is reused by the next range
+  }
+  c->n_total = n_total;
+  c->has_attr = true; c->posattr_valid = false;
+  return PT_OK;
+}
+
 int pt_build_soa(pt_ctx* c, const void* xyz, int xyz_type, const uint8_t* rgb, const float* nrm, uint64_t n, int on_device) {
   int r = pt_build_soa_indexed(c, xyz, xyz_type, nullptr, n, on_device);
   if (r != PT_OK) return r;

@@ -446,6 +446,101 @@ inline bool read_cloud_soa(const std::string& path, CloudSoA& out, long& declare
   return true;
 }
 
+// ONE PART of a cloud file for a job of `parts` cooperating readers (pointsTransfer --gpus N, host/sharded.h: rank r parses 1/N of
+// the file instead of all of it).  Part `part` owns the records that BEGIN in its share of the body:
+//   binary  records [n * part / parts, n * (part + 1) / parts) -- fixed stride, nothing to agree on;
+//   ASCII   the body is cut into `parts` byte ranges on token boundaries (the same cuts for every reader: they depend on the file
+//           only); a reader counts the tokens of its own range and `token_prefix(my_tokens, total_out)` -- the one exchange between the
+//           readers, provided by the caller -- returns the number of tokens in the ranges before it and the file's total.  Record r
+//           starts at token 9 r: the reader converts tokens [9 r0, 9 r1) for the records that begin in its range, reading the last
+//           record's tail out of the next range (at most 8 tokens) and leaving the head of a record begun earlier to its neighbour.
+// out.n = records of this part, `first_record` their global index, `total_records` the file's complete records (what
+// read_cloud_soa would deliver as out.n); record i of the part is global record first_record + i, field for field what
+// read_cloud_soa stores there.  alloc as in read_cloud_soa (five calls).  Returns false when the file cannot be opened, memory is
+// refused or token_prefix fails (returns false).
+template <class Alloc, class Prefix>
+inline bool read_cloud_soa_part(const std::string& path, int part, int parts, CloudSoA& out, uint64_t& first_record, uint64_t& total_records, long& declared,
+                                Alloc&& alloc, Prefix&& token_prefix, int threads = 0) {
+  detail::Mapping map;
+  out = CloudSoA();
+  first_record = total_records = 0;
+  if (parts < 1 || part < 0 || part >= parts || !map.open(path)) return false;
+  const Header h = parse_header_full(map.begin(), map.end());
+  declared = h.vertex_count;
+  auto allocate = [&](uint64_t n) -> bool {
+    const uint64_t a = n ? n : 1;
+    out.x = static_cast<double*>(alloc(a * 8)); out.y = static_cast<double*>(alloc(a * 8)); out.z = static_cast<double*>(alloc(a * 8));
+    out.rgb = static_cast<uint8_t*>(alloc(a * 3)); out.nrm = static_cast<float*>(alloc(a * 12));
+    out.n = (size_t)n;
+    return out.x && out.y && out.z && out.rgb && out.nrm;
+  };
+  const bool empty = declared <= 0 || h.body >= map.end();
+  if (h.binary) {
+    if (h.big_endian) return false;
+    size_t stride = 0;
+    for (int sz : h.vsize) stride += (size_t)sz;
+    const uint64_t n = (empty || !stride) ? 0 : std::min<uint64_t>((uint64_t)declared, (uint64_t)(map.end() - h.body) / stride);
+    total_records = n;
+    const uint64_t r0 = n * (uint64_t)part / (uint64_t)parts, r1 = n * (uint64_t)(part + 1) / (uint64_t)parts;
+    first_record = r0;
+    if (!allocate(r1 - r0)) return false;
+    if (r1 == r0) return true;
+    const int nprop = (int)std::min<size_t>(h.vsize.size(), 9);
+    const int th = detail::resolve_threads(threads, (size_t)(r1 - r0) * stride);
+    detail::run_parallel(th, [&](int i) {
+      const uint64_t a = r0 + (r1 - r0) * (uint64_t)i / (uint64_t)th, b = r0 + (r1 - r0) * (uint64_t)(i + 1) / (uint64_t)th;
+      const unsigned char* rec = reinterpret_cast<const unsigned char*>(h.body) + a * stride;
+      for (uint64_t r = a; r < b; ++r, rec += stride) {
+        const unsigned char* q = rec;
+        for (int f = 0; f < 9; ++f) {
+          double v = 0.0;
+          if (f < nprop) { v = detail::load_scalar(q, h.vsize[(size_t)f], h.vkind[(size_t)f]); q += h.vsize[(size_t)f]; }
+          detail::set_cloud_soa(out, r - r0, (unsigned)f, v);
+        }
+      }
+    });
+    return true;
+  }
+  // ASCII
+  const char* body = empty ? map.end() : h.body;
+  const auto rank_cuts = detail::token_cuts(body, map.end(), parts);                 // the same on every reader
+  const char *mb = rank_cuts[(size_t)part], *me = rank_cuts[(size_t)part + 1];
+  const int th = detail::resolve_threads(threads, (size_t)(me - mb));
+  const auto cuts = detail::token_cuts(mb, me, th);
+  const auto first = detail::token_offsets(cuts);                                     // pass 1 over this part only
+  uint64_t total_tokens = 0, g0 = 0;
+  if (!token_prefix(first[(size_t)th], g0, total_tokens)) return false;
+  const uint64_t n = empty ? 0 : std::min<uint64_t>((uint64_t)declared, total_tokens / 9);
+  total_records = n;
+  const uint64_t g1 = g0 + first[(size_t)th];
+  const uint64_t r0 = std::min<uint64_t>((g0 + 8) / 9, n), r1 = std::min<uint64_t>((g1 + 8) / 9, n);
+  first_record = r0;
+  if (!allocate(r1 - r0)) return false;
+  if (r1 == r0) return true;
+  const uint64_t lo = r0 * 9, hi = r1 * 9;                                            // the tokens this reader converts: [lo, hi)
+  detail::run_parallel(th, [&](int i) {
+    uint64_t g = g0 + first[(size_t)i];
+    if (g >= hi) return;
+    detail::for_each_token(cuts[(size_t)i], cuts[(size_t)i + 1], [&](const char* t, const char* e) {
+      if (g >= lo && g < hi) detail::set_cloud_soa(out, g / 9 - r0, (unsigned)(g % 9), detail::token_value(t, e));
+      ++g;
+    });
+  });
+  if (g1 < hi) {                                                                      // the last record's tail lives in the next range(s)
+    uint64_t g = g1;
+    const char* p = me;
+    while (g < hi) {
+      while (p < map.end() && is_ws(*p)) ++p;
+      if (p >= map.end()) break;                                                      // (cannot happen: n counts complete records only)
+      const char* t = p;
+      while (p < map.end() && !is_ws(*p)) ++p;
+      detail::set_cloud_soa(out, g / 9 - r0, (unsigned)(g % 9), detail::token_value(t, p));
+      ++g;
+    }
+  }
+  return true;
+}
+
 // Binary little-endian meshes (ASCII ones go through read_mesh_fast): vertices positional like the text grammar, faces from
 // the list property -- the first three indices of every face.  Same contract as read_mesh_fast.
 inline bool read_mesh_any(const std::string& path, FastMesh& mesh, int threads = 0) {

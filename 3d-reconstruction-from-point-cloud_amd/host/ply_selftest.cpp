@@ -132,6 +132,35 @@ int main(int argc, char** argv) {
           if (!same) { CHECK(!"planar record differs"); break; }
         }
         for (int c : seen) if (c != 1) { CHECK(!"a record was reported by the range callback zero or several times"); break; }
+        // the same file read by `parts` cooperating readers (read_cloud_soa_part: what the ranks of pointsTransfer --gpus N do): the parts
+        // tile the records of the whole-file read exactly, field for field
+        for (int parts : {1, 2, 3, 7}) {
+          std::vector<uint64_t> counts((size_t)parts, 0);
+          std::vector<void*> pm;
+          auto al = [&](size_t bytes) { void* q = std::malloc(bytes ? bytes : 1); pm.push_back(q); return q; };
+          for (int r = 0; r < parts; ++r) {                        // sweep 1: every reader's token count (binary files never ask)
+            ply::CloudSoA tmp; uint64_t f0 = 0, tot = 0; long d2 = 0;
+            (void)ply::read_cloud_soa_part(path, r, parts, tmp, f0, tot, d2, al, [&](uint64_t mine, uint64_t&, uint64_t&) { counts[(size_t)r] = mine; return false; }, th);
+          }
+          uint64_t total = 0, next = 0;
+          for (uint64_t c : counts) total += c;
+          for (int r = 0; r < parts; ++r) {
+            ply::CloudSoA pc; uint64_t f0 = 0, tot = 0; long d2 = 0;
+            const bool pok = ply::read_cloud_soa_part(path, r, parts, pc, f0, tot, d2, al, [&](uint64_t mine, uint64_t& before, uint64_t& all) {
+              before = 0; for (int q = 0; q < r; ++q) before += counts[(size_t)q];
+              all = total; return mine == counts[(size_t)r]; }, th);
+            CHECK(pok && d2 == want_declared && tot == got.n && f0 == next);
+            for (size_t i = 0; i < pc.n && f0 + i < got.n; ++i) {
+              const size_t g = (size_t)f0 + i;
+              const bool same = eq(pc.x[i], got.x[g]) && eq(pc.y[i], got.y[g]) && eq(pc.z[i], got.z[g]) && eq(pc.nrm[3 * i], got.nrm[3 * g]) && eq(pc.nrm[3 * i + 1], got.nrm[3 * g + 1]) &&
+                                eq(pc.nrm[3 * i + 2], got.nrm[3 * g + 2]) && pc.rgb[3 * i] == got.rgb[3 * g] && pc.rgb[3 * i + 1] == got.rgb[3 * g + 1] && pc.rgb[3 * i + 2] == got.rgb[3 * g + 2];
+              if (!same) { CHECK(!"a record of a part differs from the whole-file read"); break; }
+            }
+            next = f0 + pc.n;
+          }
+          CHECK(next == got.n);
+          for (void* q : pm) std::free(q);
+        }
         for (void* q : mem) std::free(q);
       }
     };

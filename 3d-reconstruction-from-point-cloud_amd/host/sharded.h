@@ -5,10 +5,13 @@
 //   launcher  (the process the user started; never touches a GPU) makes a rendezvous directory, starts N fresh rank processes
 //             (fork + exec of this binary with --rank r), waits for them, then starts one finalize process and waits for it.
 //   rank r    opens its GPU, joins the RCCL communicator (rank 0 writes the 128-byte id into the rendezvous directory, the others
-//             poll for it), parses the whole cloud file, keeps the points of slab r (equal-count quantiles of a sample along the
-//             longest axis -- every rank derives the same bounds from the same file), builds its grid with global indices, uploads
-//             the attribute table, searches the mesh vertices homed in its slab, completes them through the exchange, and writes
-//             its vertices' neighbour lists, blended attributes and the records of the cloud points those lists name to rank_r.bin.
+//             poll for it), parses ITS 1/N OF THE CLOUD FILE (ply::read_cloud_soa_part: a record range of a binary file, a byte
+//             range of a text file with one exchange of token counts through the rendezvous directory) and publishes the parsed
+//             piece there as a planar binary file; every rank maps all N pieces (shared page cache: the cloud is in host memory
+//             once, not N times), keeps the points of slab r (equal-count quantiles of a sample along the longest axis -- every
+//             rank derives the same bounds from the same pieces), builds its grid with global indices, uploads the attribute table
+//             piece by piece, searches the mesh vertices homed in its slab, completes them through the exchange, and writes its
+//             vertices' neighbour lists, blended attributes and the records of the cloud points those lists name to rank_r.bin.
 //   finalize  merges the rank files, builds a small cloud of the REFERENCED points only (the bake needs nothing else), remaps the
 //             neighbour lists into it, bakes and pads the texture on one GPU and writes texture.png / transfer.ply.
 // stdout keeps the reference's lines and order: rank 0 prints the read / build / search lines, finalize the draw / output lines,
@@ -16,6 +19,8 @@
 #pragma once
 #include <signal.h>
 #include <spawn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -64,19 +69,76 @@ inline bool write_all(const std::string& path, const std::vector<std::pair<const
   return ok && std::rename(tmp.c_str(), path.c_str()) == 0;     // readers never see a half-written file
 }
 
+// ---- the cloud as N pieces in the rendezvous directory --------------------------------------------------------------------------
+// piece_<r>.bin = {u64 first, u64 count} x[count] y[count] z[count] (f64) nrm[count][3] (f32) rgb[count][3] (u8): what rank r parsed.
+inline bool wait_for_file(const std::string& path, double timeout_s) {
+  const auto t0 = clk::now();
+  struct stat st;
+  while (stat(path.c_str(), &st) != 0) {
+    if (since(t0) > timeout_s) return false;
+    std::this_thread::sleep_for(std::chrono::milliseconds(5));
+  }
+  return true;
+}
+struct Piece {
+  uint64_t first = 0, count = 0;
+  const double *x = nullptr, *y = nullptr, *z = nullptr;
+  const float* nrm = nullptr;
+  const uint8_t* rgb = nullptr;
+  void* map = nullptr;
+  size_t bytes = 0;
+};
+struct Pieces {
+  std::vector<Piece> p;
+  uint64_t n = 0;
+  ~Pieces() { for (Piece& q : p) if (q.map) munmap(q.map, q.bytes); }
+  bool open(const std::string& dir, int parts, double timeout_s) {
+    for (int r = 0; r < parts; ++r) {
+      const std::string path = dir + "/piece_" + std::to_string(r) + ".bin";
+      if (!wait_for_file(path, timeout_s)) return false;
+      const int fd = ::open(path.c_str(), O_RDONLY);
+      if (fd < 0) return false;
+      struct stat st;
+      if (fstat(fd, &st) != 0 || (size_t)st.st_size < 16) { ::close(fd); return false; }
+      Piece q;
+      q.bytes = (size_t)st.st_size;
+      q.map = mmap(nullptr, q.bytes, PROT_READ, MAP_SHARED, fd, 0);
+      ::close(fd);
+      if (q.map == MAP_FAILED) { q.map = nullptr; return false; }
+      const char* b = static_cast<const char*>(q.map);
+      std::memcpy(&q.first, b, 8); std::memcpy(&q.count, b + 8, 8);
+      if (q.bytes != 16 + q.count * 39) { munmap(q.map, q.bytes); return false; }
+      q.x = reinterpret_cast<const double*>(b + 16); q.y = q.x + q.count; q.z = q.y + q.count;
+      q.nrm = reinterpret_cast<const float*>(q.z + q.count);
+      q.rgb = reinterpret_cast<const uint8_t*>(q.nrm + 3 * q.count);
+      if (q.first != n) { munmap(q.map, q.bytes); return false; }          // the pieces tile the records in rank order
+      n += q.count;
+      p.push_back(q);
+    }
+    return true;
+  }
+  // piece holding global record g (g < n)
+  const Piece& of(uint64_t g) const {
+    size_t lo = 0, hi = p.size();
+    while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (p[mid].first <= g) lo = mid; else hi = mid; }
+    return p[lo];
+  }
+};
+
 // slab bounds along `axis`: equal-count quantiles of every stride-th point (deterministic: every rank computes the same)
-inline void slab_bounds(const ply::CloudSoA& c, int world, int& axis, std::vector<double>& bounds) {
-  const size_t stride = std::max<size_t>(1, c.n / 65536);
+inline void slab_bounds(const Pieces& c, int world, int& axis, std::vector<double>& bounds) {
+  const uint64_t stride = std::max<uint64_t>(1, c.n / 65536);
   double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (size_t i = 0; i < c.n; i += stride) {
-    const double v[3] = {c.x[i], c.y[i], c.z[i]};
+  std::vector<double> sx, sy, sz;
+  for (uint64_t i = 0; i < c.n; i += stride) {
+    const Piece& q = c.of(i);
+    const double v[3] = {q.x[i - q.first], q.y[i - q.first], q.z[i - q.first]};
+    sx.push_back(v[0]); sy.push_back(v[1]); sz.push_back(v[2]);
     for (int a = 0; a < 3; ++a) { if (v[a] < mn[a]) mn[a] = v[a]; if (v[a] > mx[a]) mx[a] = v[a]; }
   }
   axis = 0;
   for (int a = 1; a < 3; ++a) if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
-  const double* src = axis == 0 ? c.x : (axis == 1 ? c.y : c.z);
-  std::vector<double> s;
-  for (size_t i = 0; i < c.n; i += stride) s.push_back(src[i]);
+  std::vector<double>& s = axis == 0 ? sx : (axis == 1 ? sy : sz);
   std::sort(s.begin(), s.end());
   bounds.assign((size_t)world + 1, 0.0);
   bounds[0] = -std::numeric_limits<double>::infinity();
@@ -121,14 +183,44 @@ inline int run_rank(const Options& o) {
     if (crc != PT_OK) return die("pt_comm_init");
   }
   pt_set_param(ctx, "k_hint", (double)o.K);
-  // ---- cloud: parsed whole (every rank reads the same file), slab r kept ------------------------------------------------
-  ply::CloudSoA cloud;
-  std::vector<void*> mem;
+  // ---- cloud: this rank parses 1/world of the file and publishes the piece; the slab is then picked from all pieces --------------
+  const double wait_s = 3600.0;                  // (peers parse as long as this rank does; a peer that DIES ends the job through the launcher)
   long declared = 0;
-  const bool opened = ply::read_cloud_soa(o.cloud, cloud, declared, [&](size_t b) { void* q = std::malloc(b ? b : 1); if (q) mem.push_back(q); return q; },
-                                          [](uint64_t) { return true; }, [](uint64_t, uint64_t) {}, o.ply_threads);
-  auto free_mem = [&]() { for (void* q : mem) std::free(q); mem.clear(); };
-  if (!opened) { if (rank == 0) std::cerr << "Cannot read or find point cloud file: " << o.cloud << std::endl; free_mem(); pt_comm_abort(ctx); pt_ctx_destroy(ctx); return 3; }
+  uint64_t my_first = 0, n_file = 0;
+  {
+    ply::CloudSoA part;
+    std::vector<void*> mem;
+    auto free_mem = [&]() { for (void* q : mem) std::free(q); mem.clear(); };
+    auto prefix = [&](uint64_t mine, uint64_t& before, uint64_t& total) -> bool {     // text files: the readers' one exchange, token counts
+      if (!write_all(o.rendezvous + "/tokens_" + std::to_string(rank), {{&mine, sizeof mine}})) return false;
+      before = total = 0;
+      for (int r = 0; r < world; ++r) {
+        const std::string f = o.rendezvous + "/tokens_" + std::to_string(r);
+        if (!wait_for_file(f, wait_s)) return false;
+        uint64_t v = 0;
+        FILE* fp = std::fopen(f.c_str(), "rb");
+        const bool ok = fp && std::fread(&v, 1, sizeof v, fp) == sizeof v;
+        if (fp) std::fclose(fp);
+        if (!ok) return false;
+        if (r < rank) before += v;
+        total += v;
+      }
+      return true;
+    };
+    const bool opened = ply::read_cloud_soa_part(o.cloud, rank, world, part, my_first, n_file, declared,
+                                                 [&](size_t b) { void* q = std::malloc(b ? b : 1); if (q) mem.push_back(q); return q; }, prefix, o.ply_threads);
+    if (!opened) { if (rank == 0) std::cerr << "Cannot read or find point cloud file: " << o.cloud << std::endl; free_mem(); pt_comm_abort(ctx); pt_ctx_destroy(ctx); return 3; }
+    if (n_file >= 0xFFFFFFF0ull) { free_mem(); pt_comm_abort(ctx); std::cerr << "pointsTransfer[rank " << rank << "]: " << n_file << " points: indices are 32-bit on this path (< 2^32 - 16 points)" << std::endl; pt_ctx_destroy(ctx); return 1; }
+    const uint64_t hdr[2] = {my_first, (uint64_t)part.n};
+    const bool wrote = write_all(o.rendezvous + "/piece_" + std::to_string(rank) + ".bin",
+                                 {{hdr, sizeof hdr}, {part.x, part.n * 8}, {part.y, part.n * 8}, {part.z, part.n * 8}, {part.nrm, part.n * 12}, {part.rgb, part.n * 3}});
+    std::cerr << "[pt_hip rank " << rank << "] parsed records [" << my_first << ", " << my_first + part.n << ") of " << n_file << " (1/" << world << " of the file) in "
+              << since(t_task) << " s" << std::endl;
+    free_mem();
+    if (!wrote) return die("cannot write this rank's piece of the cloud into the rendezvous directory");
+  }
+  Pieces cloud;
+  if (!cloud.open(o.rendezvous, world, wait_s) || cloud.n != n_file) return die("the pieces of the cloud in the rendezvous directory are incomplete");
   if (rank == 0) {
     std::cout << "PC Point count: " << declared << std::endl;
     std::cout << "Read point set in: " << since(t_task) << " seconds" << std::endl;
@@ -138,19 +230,29 @@ inline int run_rank(const Options& o) {
   std::vector<double> bounds;
   slab_bounds(cloud, world, axis, bounds);
   const double lo = bounds[(size_t)rank], hi = bounds[(size_t)rank + 1];
-  const double* ax = axis == 0 ? cloud.x : (axis == 1 ? cloud.y : cloud.z);
   std::vector<uint32_t> gidx;
-  for (size_t i = 0; i < cloud.n; ++i) if (ax[i] >= lo && ax[i] < hi) gidx.push_back((uint32_t)i);
+  std::vector<double> sx, sy, sz;
+  for (const Piece& q : cloud.p) {
+    const double* ax = axis == 0 ? q.x : (axis == 1 ? q.y : q.z);
+    for (uint64_t i = 0; i < q.count; ++i)
+      if (ax[i] >= lo && ax[i] < hi) { gidx.push_back((uint32_t)(q.first + i)); sx.push_back(q.x[i]); sy.push_back(q.y[i]); sz.push_back(q.z[i]); }
+  }
   const size_t ns = gidx.size();
-  std::vector<double> sxyz(std::max<size_t>(ns, 1) * 3);
-  for (size_t j = 0; j < ns; ++j) { sxyz[j] = cloud.x[gidx[j]]; sxyz[ns + j] = cloud.y[gidx[j]]; sxyz[2 * ns + j] = cloud.z[gidx[j]]; }
-  if (pt_build_soa_indexed(ctx, sxyz.data(), PT_F64, gidx.data(), ns, 0) != PT_OK) return die("build failed");
-  if (pt_set_attributes(ctx, cloud.rgb, cloud.nrm, cloud.n, 0) != PT_OK) return die("attribute upload failed");
+  {
+    std::vector<double> sxyz(std::max<size_t>(ns, 1) * 3);
+    std::copy(sx.begin(), sx.end(), sxyz.begin()); std::copy(sy.begin(), sy.end(), sxyz.begin() + (long)ns); std::copy(sz.begin(), sz.end(), sxyz.begin() + 2 * (long)ns);
+    std::vector<double>().swap(sx); std::vector<double>().swap(sy); std::vector<double>().swap(sz);
+    if (pt_build_soa_indexed(ctx, sxyz.data(), PT_F64, gidx.data(), ns, 0) != PT_OK) return die("build failed");
+  }
+  // the attribute table (indexed by global index, replicated on every GPU so that the blend is local) straight from the mapped pieces
+  for (const Piece& q : cloud.p)
+    if (pt_set_attributes_range(ctx, q.first, q.count, q.rgb, q.nrm, cloud.n) != PT_OK) return die("attribute upload failed");
+  if (!cloud.n && pt_set_attributes_range(ctx, 0, 0, nullptr, nullptr, 0) != PT_OK) return die("attribute upload failed");
   if (rank == 0) std::cout << "Built Kd tree in: " << since(t_task) << " seconds" << std::endl;
   t_task = clk::now();
   // ---- mesh: the vertices homed in this slab ---------------------------------------------------------------------------------
   ply::FastMesh mesh;
-  if (!ply::read_mesh_any(o.mesh, mesh, o.ply_threads)) { if (rank == 0) std::cerr << "Cannot read or find mesh file: " << o.mesh << std::endl; free_mem(); pt_comm_abort(ctx); pt_ctx_destroy(ctx); return 3; }
+  if (!ply::read_mesh_any(o.mesh, mesh, o.ply_threads)) { if (rank == 0) std::cerr << "Cannot read or find mesh file: " << o.mesh << std::endl; pt_comm_abort(ctx); pt_ctx_destroy(ctx); return 3; }
   if (rank == 0) {
     std::cout << "Mesh vertex count: " << mesh.vertex_count << std::endl;
     std::cout << "Mesh face count: " << mesh.face_count << std::endl;
@@ -177,8 +279,10 @@ inline int run_rank(const Options& o) {
   std::vector<RefPoint> pts(ref.size());
   for (size_t j = 0; j < ref.size(); ++j) {
     const uint32_t id = ref[j];
-    pts[j].id = id; pts[j].x = cloud.x[id]; pts[j].y = cloud.y[id]; pts[j].z = cloud.z[id];
-    std::memcpy(pts[j].rgb, cloud.rgb + 3 * (size_t)id, 3);
+    const Piece& q = cloud.of(id);
+    const uint64_t li = id - q.first;
+    pts[j].id = id; pts[j].x = q.x[li]; pts[j].y = q.y[li]; pts[j].z = q.z[li];
+    std::memcpy(pts[j].rgb, q.rgb + 3 * li, 3);
   }
   const uint64_t hdr[4] = {(uint64_t)mh, (uint64_t)o.K, (uint64_t)pts.size(), (uint64_t)cloud.n};
   const bool ok = write_all(o.rendezvous + "/rank_" + std::to_string(rank) + ".bin",
@@ -186,7 +290,6 @@ inline int run_rank(const Options& o) {
                              {nrm.data(), nrm.size() * 4}, {pts.data(), pts.size() * sizeof(RefPoint)}});
   std::cerr << "[pt_hip rank " << rank << "] slab " << ns << " points, " << mh << " home vertices, " << xs.crossing << " requests out, " << xs.answered
             << " answered, exchange " << xs.ms << " ms, " << since(t_start) << " s in all" << std::endl;
-  free_mem();
   pt_comm_destroy(ctx);
   pt_ctx_destroy(ctx);
   return ok ? 0 : 1;
@@ -315,7 +418,8 @@ inline int run_launcher(const Options& o, const std::string& self, const std::ve
   for (int r = 0; r < o.gpus; ++r) ranks.push_back(cmd_for({"--rank", std::to_string(r)}));
   int rc = spawn_and_wait(ranks);
   if (rc == 0) rc = spawn_and_wait({cmd_for({"--finalize"})});
-  for (int r = 0; r < o.gpus; ++r) std::remove((dir + "/rank_" + std::to_string(r) + ".bin").c_str());
+  for (int r = 0; r < o.gpus; ++r)
+    for (const char* f : {"/rank_", "/piece_", "/tokens_"}) { std::remove((dir + f + std::to_string(r) + (f[1] == 't' ? "" : ".bin")).c_str()); std::remove((dir + f + std::to_string(r) + (f[1] == 't' ? "" : ".bin") + ".part").c_str()); }
   std::remove((dir + "/rccl_id").c_str());
   rmdir(dir.c_str());
   return rc == 3 ? 0 : rc;          // 3: an input file could not be read -- reported, exit code 0 as the reference (:140, :272)

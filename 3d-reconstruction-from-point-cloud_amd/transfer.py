@@ -139,6 +139,13 @@ class PointsTransfer:
         n = (r if r is not None else m).shape[0]
         self._chk(self._L.pt_set_attributes(self._h, _ptr(r), _ptr(m), n, 0))
 
+    def set_attributes_range(self, first, rgb, nrm, n_total):
+        """Records [first, first + len) of the attribute table of n_total points, from host arrays (rgb [c,3] u8, nrm [c,3] f32)."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8) if rgb is not None else None
+        nrm = np.ascontiguousarray(nrm, dtype=np.float32) if nrm is not None else None
+        count = len(rgb) if rgb is not None else len(nrm)
+        self._chk(self._L.pt_set_attributes_range(self._h, int(first), int(count), _ptr(rgb), _ptr(nrm), int(n_total)))
+
     def build_synth(self, n_total, seed, xyz_type=capi.F32, dist=capi.DIST_UNIFORM, slab_axis=-1, slab_lo=-math.inf, slab_hi=math.inf):
         self._chk(self._L.pt_build_synth(self._h, n_total, seed, dist, xyz_type, slab_axis, slab_lo, slab_hi))
 

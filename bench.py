@@ -132,6 +132,90 @@ def cpu_baseline(n_total, m_total, k, seed):
     }
 
 
+class BoxSampler:
+    """What the GPU this rank runs on is SET to and what it DOES while the timed steps run (the same binary is 49.5 ms on
+    one MI355X and 54.2 on another -- the JSON line now says what the box looked like).  The card is found in sysfs by PCI address
+    (torch's device properties; no extra GPU call); a host thread reads shader clock, socket power, temperatures and the busy
+    percentages every few milliseconds between start() and stop().  Host-side file reads only: nothing is added to the GPU's queue."""
+
+    def __init__(self, torch, index):
+        import glob
+        self.dir = self.hwmon = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+                if "-" in os.path.basename(card):
+                    continue
+                if os.path.basename(os.path.realpath(os.path.join(card, "device"))).lower().startswith(want):
+                    self.dir = os.path.join(card, "device")
+                    hw = glob.glob(os.path.join(self.dir, "hwmon", "hwmon*"))
+                    self.hwmon = hw[0] if hw else None
+        except Exception:           # noqa: BLE001 -- a box that hides sysfs just reports nothing
+            pass
+        self.samples = []
+        self._stop = None
+        self._thread = None
+
+    @staticmethod
+    def _rd(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+
+    def _num(self, base, name, scale):
+        v = self._rd(os.path.join(base, name)) if base else None
+        try:
+            return float(v) * scale
+        except (TypeError, ValueError):
+            return None
+
+    def static(self):
+        if not self.dir:
+            return {"card": None}
+        level = lambda f: next((l.split(":")[1].strip().rstrip("*").strip() for l in (self._rd(os.path.join(self.dir, f)) or "").splitlines() if l.endswith("*")), None)
+        return {"card": os.path.basename(os.path.dirname(self.dir)), "pci": os.path.basename(os.path.realpath(self.dir)),
+                "compute_partition": self._rd(os.path.join(self.dir, "current_compute_partition")),
+                "memory_partition": self._rd(os.path.join(self.dir, "current_memory_partition")),
+                "perf_level": self._rd(os.path.join(self.dir, "power_dpm_force_performance_level")),
+                "sclk_levels": (self._rd(os.path.join(self.dir, "pp_dpm_sclk")) or "").replace("\n", " | "),
+                "mclk_mhz": level("pp_dpm_mclk"), "fclk_mhz": level("pp_dpm_fclk"),
+                "power_cap_w": self._num(self.hwmon, "power1_cap", 1e-6), "vbios": self._rd(os.path.join(self.dir, "vbios_version"))}
+
+    def _one(self):
+        return (self._num(self.hwmon, "freq1_input", 1e-6), self._num(self.hwmon, "power1_input", 1e-6), self._num(self.hwmon, "temp2_input", 1e-3),
+                self._num(self.hwmon, "temp3_input", 1e-3), self._num(self.dir, "gpu_busy_percent", 1.0), self._num(self.dir, "mem_busy_percent", 1.0))
+
+    def start(self, period=0.004):
+        if not self.dir:
+            return
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append(self._one())
+                self._stop.wait(period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread:
+            self._stop.set()
+            self._thread.join()
+
+    def summary(self):
+        out = self.static()
+        cols = ("sclk_mhz", "power_w", "temp_junction_c", "temp_mem_c", "gpu_busy_pct", "mem_busy_pct")
+        for i, name in enumerate(cols):
+            v = [t[i] for t in self.samples if t[i] is not None]
+            out[name] = {"min": min(v), "mean": round(sum(v) / len(v), 1), "max": max(v)} if v else None
+        out["samples"] = len(self.samples)
+        return out
+
+
 def dry_run(args, world, rank, dist, torch):
     """--dry-run: everything of a multi-rank run EXCEPT the GPU work -- rendezvous, the fence, K "steps" (a sleep), the max over ranks,
     one JSON line from rank 0 -- so that the launcher and the collectives' plumbing are testable on a machine without GPUs."""
@@ -370,14 +454,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    box = BoxSampler(torch, local_rank)
     for _ in range(args.warmup):
         step(False)
     fence()
+    box.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     fence()
     dt = time.perf_counter() - t0
+    box.stop()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -389,11 +476,12 @@ def main():
         K = args.steps
         kavg = [v / K for v in kms]
         dom = max(range(8), key=lambda i: kavg[i])
-        alg = survey_alg_bytes(KERNEL_NAMES[dom], n_loc, m_loc, k)          # what frac is quoted on
-        impl = kernel_alg_bytes(KERNEL_NAMES[dom], n_loc, m_loc, k)        # this build's own minimum, for comparison only
+        sx = 6 if type_name == "f16" else 12                                  # s = bytes per xyz (fp16 clouds: 6)
+        alg = survey_alg_bytes(KERNEL_NAMES[dom], n_loc, m_loc, k, sx)      # what frac is quoted on
+        impl = kernel_alg_bytes(KERNEL_NAMES[dom], n_loc, m_loc, k)        # this build's own minimum (its sorted records are fp32 either way), for comparison only
         achieved = alg / (kavg[dom] * 1e-3) / 1e9
         _, pmc_file = pmc_profile(args.workload, world)
-        b_alg_job = n_total * 28 + (n_total * 12 + m_total * 12 + m_total * k * 16 + m_total * (4 * k + 24))
+        b_alg_job = n_total * (2 * sx + 4) + (n_total * sx + m_total * sx + m_total * k * 16 + m_total * (4 * k + 24))   # B_build + B_query
         out = {
             "metric": "target points/sec (k=%d detail transfer)" % k,
             "value": value, "unit": "target points/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -416,6 +504,9 @@ def main():
             "kernels_ms": dict(zip(KERNEL_NAMES, [round(v, 4) for v in kavg])),
             "phases_ms": {a: round(b / K, 4) for a, b in phase.items()},
             "rank0": {"n_source": n_loc, "n_target": m_loc, "exchange": xstats},
+            # the state of rank 0's GPU over the timed steps (sysfs, sampled by a host thread) and what the pass-1 scatter -- the kernel
+            # whose time moves most from box to box -- reached on it: 12 B read + 16 B record + 2 B id written per source point
+            "box": dict(box.summary(), pass1_scatter_gbs=round(n_loc * 30 / (kavg[2] * 1e-3) / 1e9, 1) if kavg[2] > 0 else None),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n_total, m_total, k, seed)

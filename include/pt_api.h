@@ -138,6 +138,11 @@ int  pt_build_soa_indexed(pt_ctx*, const void* xyz, int xyz_type, const uint32_t
                           int on_device);
 /* Attribute table indexed by global index (the whole cloud's, on every GPU). */
 int  pt_set_attributes(pt_ctx*, const uint8_t* rgb, const float* nrm, uint64_t n_total, int on_device);
+/* The same table filled piecewise from HOST memory: records [first, first + count) of a table of n_total (the first call, or a
+ * change of n_total, allocates it zeroed).  For hosts that hold the attributes in pieces -- the ranks of `pointsTransfer --gpus N`
+ * each parse 1/N of the file and read the other pieces from the rendezvous directory -- so that no rank ever assembles the whole
+ * table in host memory. */
+int  pt_set_attributes_range(pt_ctx*, uint64_t first, uint64_t count, const uint8_t* rgb, const float* nrm, uint64_t n_total);
 /* SURVEY.md Appendix C generator, on the device.  Keeps the points whose coordinate along
  * `slab_axis` lies in [slab_lo, slab_hi) (pass -inf/+inf, or slab_axis < 0, for the whole cloud);
  * indices stay global; the attribute table is generated for all n_total points. */

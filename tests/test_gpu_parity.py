@@ -2,6 +2,7 @@
 Bar: neighbour indices and squared distances bit-exact; blended attributes within 1e-5 (colour/255, normals)."""
 import math
 import os
+import re
 import subprocess
 import sys
 
@@ -1131,8 +1132,30 @@ def test_native_exchange_two_ranks_over_rccl(pkg, oracle, tmp_path):
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
 
 
-@pytest.mark.parametrize("gpus", [1, 2])
-def test_cli_sharded_path(tmp_path, pkg, oracle, gpus):
+def test_attribute_table_filled_in_ranges(pkg, oracle):
+    """pt_set_attributes_range (what the ranks of `pointsTransfer --gpus N` feed from the pieces of the cloud): the table filled in
+    three uneven ranges blends exactly like the table uploaded whole; a range outside the table is refused."""
+    n, m, k = 30000, 700, 8
+    src, tgt = oracle.synth_xyz(21, 0, n), oracle.synth_xyz(21, 1, m)
+    rgb, nrm = oracle.synth_rgb(21, n), oracle.synth_nrm(21, n)
+    with pkg.PointsTransfer(device=0) as a, pkg.PointsTransfer(device=0) as b:
+        a.build(src, rgb, nrm)
+        b.build(src)
+        for lo, hi in ((0, 1), (1, 17001), (17001, n)):
+            b.set_attributes_range(lo, rgb[lo:hi], nrm[lo:hi], n)
+        ia, da = a.query(tgt, k)
+        ib, db = b.query(tgt, k)
+        assert np.array_equal(ia, ib)
+        for mode in (pkg.BLEND_MEAN, pkg.BLEND_INV_D2):
+            ca, na = a.blend(ia, da, mode=mode)
+            cb, nb = b.blend(ib, db, mode=mode)
+            assert np.array_equal(ca, cb) and np.array_equal(na, nb)
+        with pytest.raises(pkg.PtError):
+            b.set_attributes_range(n - 1, rgb[:2], nrm[:2], n)
+
+
+@pytest.mark.parametrize("gpus,fmt", [(1, "binary"), (1, "ascii"), (2, "binary"), (2, "ascii")])
+def test_cli_sharded_path(tmp_path, pkg, oracle, gpus, fmt):
     """pointsTransfer ... --gpus N: launcher -> one rank process per GPU (RCCL communicator, slab build with global indices, home
     search, native exchange) -> finalize (bake on the referenced points only).  texture.png must equal the single-process run's
     byte for byte after decoding; --gpus 1 runs everywhere, --gpus 2 needs two GPUs."""
@@ -1142,7 +1165,7 @@ def test_cli_sharded_path(tmp_path, pkg, oracle, gpus):
     from _bake_cases import make_case
     src, rgb, verts, uv, vrgb, faces = make_case(13, n=9000, grid=5)
     pc, mesh = tmp_path / "cloud.ply", tmp_path / "mesh.ply"
-    _write_binary_plys(pc, mesh, src, rgb, verts, uv, vrgb, faces)
+    (_write_binary_plys if fmt == "binary" else _write_ascii_plys)(pc, mesh, src, rgb, verts, uv, vrgb, faces)
     exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "pointsTransfer")
     d1, d2_ = tmp_path / "single", tmp_path / "sharded"
     d1.mkdir(); d2_.mkdir()
@@ -1158,6 +1181,10 @@ def test_cli_sharded_path(tmp_path, pkg, oracle, gpus):
     # the launcher removes its rendezvous directory: none of THIS run's may be left (named in its stderr line, see run_launcher)
     left = [l.split()[-1] for l in r2.stderr.splitlines() if l.startswith("[pt_hip launcher] rendezvous")]
     assert left and not any(os.path.exists(d) for d in left)
+    # every rank parsed its own share of the cloud file, and the shares tile it
+    parsed = sorted(tuple(int(v) for v in re.findall(r"parsed records \[(\d+), (\d+)\) of (\d+)", l)[0]) for l in r2.stderr.splitlines() if "parsed records" in l)
+    assert len(parsed) == gpus and parsed[0][0] == 0 and parsed[-1][1] == parsed[-1][2] == src.shape[1]
+    assert all(parsed[i][1] == parsed[i + 1][0] for i in range(gpus - 1))
 
 
 # ---- refined cells (pt_refine.hip): sub-grids inside heavy cells, descended into by the group kernel ---------------------------

@@ -8,7 +8,7 @@ cur = None
 for line in out.splitlines():
     m = re.search(r"Function Name: (\S+)", line)
     if m:
-        cur = {"name": subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()[:70]}
+        cur = {"name": subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip().replace("(anonymous namespace)::", "")[:110]}
         continue
     if cur is None:
         if "error" in line: print(line)
@@ -18,5 +18,5 @@ for line in out.splitlines():
         if m: cur[key.split(" ")[0]] = int(m.group(1))
     if "LDS Size" in line:
         if flt in cur["name"]:
-            print("%-72s vgpr %3d sgpr %3d scratch %4d occ %d lds %6d" % (cur["name"], cur.get("VGPRs", -1), cur.get("TotalSGPRs", -1), cur.get("ScratchSize", -1), cur.get("Occupancy", -1), cur.get("LDS", -1)))
+            print("%-112s vgpr %3d sgpr %3d scratch %4d occ %d lds %6d" % (cur["name"], cur.get("VGPRs", -1), cur.get("TotalSGPRs", -1), cur.get("ScratchSize", -1), cur.get("Occupancy", -1), cur.get("LDS", -1)))
         cur = None
