@@ -61,6 +61,9 @@ struct pt_ctx {
   bool has_gidx = false, has_attr = false, built = false, posattr_valid = false;
   uint64_t guess_min_points = 8u << 20;   // clouds at least this large lay their grid out from a sampled bounding box
   bool bbox_guess_ok = true;   // big clouds: lay the grid out from a sampled bounding box (cleared when a guess failed; reset by an upload)
+  bool pool_ok = true;         // big clouds, two-level sorts: pass 1 without its histogram pass (cleared when a bin outgrew its sampled region; reset by an upload)
+  uint64_t pool_min_points = 32u << 20;   // ... from this size up ("pool_min_points"; 0 switches the pooled pass 1 off)
+  int n_cu = 256;              // compute units of the device: persistent workgroups of the pooled pass 1
   GridParams gp{};
   SortTables stb{};
   DevBuf stb_mem;
@@ -163,7 +166,7 @@ int finish(pt_ctx* c) {
 }
 
 // carve the SortTables of one sort out of a single allocation
-int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32_t npoints, size_t rec_size) {
+int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32_t npoints, size_t rec_size, uint64_t pool_records = 0) {
   const size_t small = PT_MAXBINS + 8;
   const size_t words = small * 4 /*counts1,start1,cursor1,tile_first2*/ + 16 /*tile_first1, seg_start1*/ +
                        ((size_t)nblocks + 8) * 3 + ((size_t)nblocks / 2048 + 16);
@@ -171,9 +174,10 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
   const size_t nmac = nblocks / PT_MACRO_BLOCKS, ngrp = (nmac + ((size_t)1 << gsh) - 1) >> gsh, nmacP = ngrp << gsh;
   const size_t nchunks = pt_sort_num_chunks(npoints, rec_size), nbins1 = ngrp + 1;
   const size_t chunk_words = nblocks > PT_MAXBINS ? (nchunks + 1) * nbins1 + (nchunks / 64 + 2) * nbins1 : 0;
-  const size_t bid_words = nblocks > PT_MAXBINS && !gsh ? ((size_t)npoints + 3) / 2 + 12 : 0;     // u16 per point, two-level sorts only; 16-byte aligned, 16 bytes of slack (read 8 at a time)
+  const size_t bid_points = std::max<uint64_t>(npoints, pool_records);             // (the pooled pass 1 writes ids for its slack and scratch area too)
+  const size_t bid_words = nblocks > PT_MAXBINS && !gsh ? (bid_points + 3) / 2 + 12 : 0;     // u16 per point, two-level sorts only; 16-byte aligned, 16 bytes of slack (read 8 at a time)
   const size_t mac_words = gsh ? (nmacP + 8) * 4 : 0;
-  RES(c, mem, (words + chunk_words + bid_words + mac_words + 16) * sizeof(uint32_t));
+  RES(c, mem, (words + chunk_words + bid_words + mac_words + 16 + 2 * small + 8) * sizeof(uint32_t));
   uint32_t* p = (uint32_t*)mem.p;
   tb.counts1 = p; p += small;
   tb.start1 = p; p += small;
@@ -192,6 +196,8 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
   p += bid_words ? bid_words - 4 : 0;
   tb.countsM = tb.startM = tb.cursorM = tb.tile_firstM = nullptr;
   if (gsh) { tb.countsM = p; p += nmacP + 8; tb.startM = p; p += nmacP + 8; tb.cursorM = p; p += nmacP + 8; tb.tile_firstM = p; p += nmacP + 8; }
+  tb.pool_est = p; p += small; tb.pool_limit = p; p += small; tb.pool_flag = p; p += 8;
+  tb.pool_records = pool_records; tb.pool_nwg = (uint32_t)c->n_cu;
   tb.occupied = nullptr;
   tb.shadow32 = nullptr;
   tb.status = nullptr;
@@ -319,6 +325,7 @@ int rebuild(pt_ctx* c) {
   size_t ncells = 0;
   c->st.n_refine = 0;
   uint32_t max_cell = 0;            // points of the fullest cell of the final grid (adaptive builds)
+  bool pool_failed = false;         // the pooled pass 1 overflowed a region and the build was redone with the exact pass 1
   for (int iter = 0;; ++iter) {
     choose_grid(c, mn, mx, force_h);
     if (guessed && iter == 0) {           // widen the sampled box into the grid's own padding; no room on some axis: no guess
@@ -339,9 +346,15 @@ int rebuild(pt_ctx* c) {
     nblocks = (uint32_t)c->gp.nblocks;
     ncells = (size_t)nblocks * PT_BLOCK_CELLS;
     RES(c, c->cell_start, (ncells + 1) * sizeof(uint32_t));
-    RES(c, c->rec, std::max<size_t>(c->n, 1) * recsize(c->src_type));
+    // big clouds on the two-level sort: pass 1 takes its bin regions from a sample instead of a histogram pass of its own (pt_grid.hip,
+    // scatter_pool_kernel); its output -- the records array -- then carries slack between the bins and a scratch area
+    uint64_t pool_records = 0;
+    if (c->pool_ok && c->pool_min_points && c->n >= c->pool_min_points && nblocks > PT_MAXBINS && !pt_sort_group_shift(nblocks))
+      pool_records = pt_sort_pool_records((uint32_t)c->n, nblocks / PT_MACRO_BLOCKS, (uint32_t)c->n_cu, recsize(c->src_type));
+    RES(c, c->rec, std::max<size_t>(std::max<uint64_t>(c->n, pool_records), 1) * recsize(c->src_type));
     RES(c, c->rec_tmp, std::max<size_t>(c->n, 1) * recsize(c->src_type));
-    { int r = make_tables(c, c->stb_mem, c->stb, nblocks, (uint32_t)c->n, recsize(c->src_type)); if (r != PT_OK) return r; }
+    { int r = make_tables(c, c->stb_mem, c->stb, nblocks, (uint32_t)c->n, recsize(c->src_type), pool_records); if (r != PT_OK) return r; }
+    c->st.pass1_pooled = pool_failed ? -1 : (pool_records ? 1 : 0);
     c->stb.ev = c->sev;
     c->rec32_valid = false;
     if (c->src_type == PT_F64 && c->tile && c->n) {           // the tile kernel's fp32 image of an fp64 cloud, written by finalize
@@ -354,6 +367,10 @@ int rebuild(pt_ctx* c) {
     if (verify) pt_launch_bbox_init((uint64_t*)c->bbox6.p, c->stream);
     uint64_t* bv = verify ? (uint64_t*)c->bbox6.p : nullptr;
     { const int r = c->in_half ? run_source_sort<__half, RecF>(c, bv) : (c->src_type == PT_F32 ? run_source_sort<float, RecF>(c, bv) : run_source_sort<double, RecD>(c, bv)); if (r != PT_OK) return r; }
+    if (pool_records) {       // did every bin stay inside the region its sample gave it?  (read with the bounding box below when there is one)
+      HIPCHK(c, hipMemcpyAsync(c->h_counter + 15, c->stb.pool_flag, 4, hipMemcpyDeviceToHost, c->stream));
+      if (!verify) HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     if (verify) {
       HIPCHK(c, hipMemcpyAsync(c->h_bbox, c->bbox6.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -369,9 +386,17 @@ int rebuild(pt_ctx* c) {
         c->bbox_guess_ok = false;
         guessed = false;
         force_h = 0.0;
+        if (pool_records && c->h_counter[15]) c->pool_ok = false;
         --iter;
         continue;
       }
+    }
+    if (pool_records && c->h_counter[15]) {       // a bin outgrew its region (the sample missed a cluster): the same grid again, exactly, and no
+      c->pool_ok = false;                         // more pooling for this cloud
+      pool_failed = true;
+      guessed = false;                            // (the box is exact by now, or was never guessed)
+      --iter;
+      continue;
     }
     c->st.rho_occupied = 0.0;
     if (!c->adaptive || !c->n) break;
@@ -759,6 +784,7 @@ int pt_ctx_create(pt_ctx** out, const int* device_ids, int n_devices) {
   c->device = dev;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERR_HIP; }
   c->stream = c->own_stream;
+  { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) c->n_cu = cu; }
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return PT_ERR_HIP; }
   for (auto& e : c->sev)
@@ -823,6 +849,7 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!strcmp(name, "wave_force")) { c->wave_force = value != 0; return PT_OK; }
   if (!strcmp(name, "wave_min")) { if (!(value >= 0 && value <= 4e9)) return fail(c, PT_ERR_ARG, "wave_min out of range"); c->wave_min = (uint32_t)value; return PT_OK; }
   if (!strcmp(name, "refine_threshold")) { if (!(value >= 0 && value <= 1e9)) return fail(c, PT_ERR_ARG, "refine_threshold out of range"); c->refine_threshold = value; return PT_OK; }
+  if (!strcmp(name, "pool_min_points")) { c->pool_min_points = value < 0 ? 0 : (uint64_t)value; c->pool_ok = true; return PT_OK; }   // pooled pass 1 from this size up (0: never)
   if (!strcmp(name, "guess_min_points")) { c->guess_min_points = value < 1 ? 1 : (uint64_t)value; return PT_OK; }   // sampled-bbox builds from this size up   // 0 group kernel only, 1 auto, 2 small tiles, 3 large tiles
   if (!strcmp(name, "own_stream")) { if (value != 0) c->stream = c->own_stream; return PT_OK; }
   return fail(c, PT_ERR_ARG, "unknown parameter '%s'", name);
@@ -858,7 +885,7 @@ int pt_build_aos(pt_ctx* c, const pt_point* cloud, uint64_t n) {
   { int r = copy_in(c, c->aos_stage.p, cloud, n * sizeof(pt_point), 0); if (r) return r; }
   double* x = (double*)c->in_xyz.p;
   pt_launch_aos_split(c->aos_stage.p, (uint32_t)n, x, x + n, x + 2 * n, (Attr*)c->attr.p, c->stream);
-  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
+  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -881,7 +908,7 @@ int pt_build_soa_indexed(pt_ctx* c, const void* xyz, int xyz_type, const uint32_
   }
   c->src_type = xyz_type; c->n = n; c->has_gidx = gidx != nullptr; c->built = false;
   if (!gidx) { c->n_total = n; c->has_attr = false; }
-  c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
+  c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -963,7 +990,7 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
   else { double* x = (double*)c->in_xyz.p; pt_launch_synth_xyz<double>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream); }
   RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
   pt_launch_synth_attr(seed, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
-  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
+  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -1339,7 +1366,7 @@ int pt_upload_end(pt_ctx* c) {
   if (c->up_attr) pt_launch_pack_attr((const uint8_t*)c->up_rgb.p, (const float*)c->up_nrm.p, (uint32_t)n, (Attr*)c->attr.p, c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));                                // the caller's buffers are free again
   c->src_type = c->up_type; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = c->up_attr != 0; c->built = false;
-  c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
+  c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
   c->up_type = -1;
   release(c, c->up_rgb); release(c, c->up_nrm);
   return rebuild(c);
@@ -1406,7 +1433,7 @@ int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64
       HIPCHK(c, hipStreamWaitEvent(c->stream, copied[b], 0));
       c->in_xyz = stage[b];
       c->src_type = xyz_type; c->n = cnt; c->n_total = cnt; c->has_gidx = false; c->has_attr = false; c->built = false;
-      c->posattr_valid = false; c->bbox_guess_ok = true; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
+      c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
       { int r = rebuild(c); if (r) return r; }
       HIPCHK(c, hipEventRecord(consumed[b], c->stream));               // the build no longer reads stage[b] (records hold the coordinates)
       { int r = run_query(c, c->t_xyz.p, c->tgt_type, m, k, nullptr, (uint32_t*)ci.p, (double*)cd.p); if (r) return r; }

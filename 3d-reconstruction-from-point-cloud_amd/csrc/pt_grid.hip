@@ -88,8 +88,11 @@ __device__ inline uint32_t block_of_rec(const GridParams& gp, const Rec& r) {
 }
 
 // tile -> (segment, [s,e)).  tile_first is the exclusive scan of tiles per segment (nseg+1 entries).
+// seg_end: null when the segments are dense (segment i ends where i + 1 starts); the pooled pass 1 leaves slack between its bins and
+// says where each one ends.
 __device__ inline bool tile_range(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ tile_first, int nseg,
-                                  uint32_t tile, uint32_t tile_pts, uint32_t& seg, uint32_t& s, uint32_t& e) {
+                                  uint32_t tile, uint32_t tile_pts, uint32_t& seg, uint32_t& s, uint32_t& e,
+                                  const uint32_t* __restrict__ seg_end = nullptr) {
   if (tile >= tile_first[nseg]) return false;
   int lo = 0, hi = nseg;               // invariant: tile_first[lo] <= tile < tile_first[hi]
   while (hi - lo > 1) {
@@ -98,7 +101,7 @@ __device__ inline bool tile_range(const uint32_t* __restrict__ seg_start, const 
   }
   seg = (uint32_t)lo;
   s = seg_start[lo] + (tile - tile_first[lo]) * tile_pts;
-  const uint32_t send = seg_start[lo + 1];
+  const uint32_t send = seg_end ? seg_end[lo] : seg_start[lo + 1];
   e = (send - s > tile_pts) ? s + tile_pts : send;
   return true;
 }
@@ -302,17 +305,20 @@ __global__ __launch_bounds__(WG) void hist_kernel(Loader in, GridParams gp, BinS
 template <class Loader, int ITEMS, int SW>
 __global__ __launch_bounds__(SW) void scatter_kernel(Loader in, typename Loader::Rec* __restrict__ out, GridParams gp, BinSpec bs,
                                                      const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ tile_first, int nseg,
-                                                     uint32_t* cursor) {
+                                                     uint32_t* cursor, const uint32_t* __restrict__ seg_end = nullptr) {
   using Rec = typename Loader::Rec;
   constexpr uint32_t TILE = SW * ITEMS;
   constexpr int BPT = PT_MAXBINS / SW;            // bins per thread in the scan
+  // seg_end != null: the input is what the pooled pass 1 wrote -- segments with slack between them and, inside them, the SENTINEL
+  // records (id = PT_NOIDX_U) that pad the blocks a workgroup left partly filled; those are dropped here.
+  const bool skip = seg_end != nullptr;
   __shared__ uint32_t binA[PT_MAXBINS];           // counts, then local start of each bin in `stage`
   __shared__ uint32_t binB[PT_MAXBINS];           // global start of the bin's run minus its local start
   __shared__ uint32_t wsum[SW / 64];
   __shared__ Rec stage[TILE];
 
   uint32_t seg, s, e;
-  if (!tile_range(seg_start, tile_first, nseg, blockIdx.x, TILE, seg, s, e) || e <= s) return;      // (workgroup-uniform; tiles are never empty)
+  if (!tile_range(seg_start, tile_first, nseg, blockIdx.x, TILE, seg, s, e, seg_end) || e <= s) return;      // (workgroup-uniform; tiles are never empty)
   for (int b = threadIdx.x; b < PT_MAXBINS; b += SW) binA[b] = 0;
   __syncthreads();
 
@@ -327,21 +333,23 @@ __global__ __launch_bounds__(SW) void scatter_kernel(Loader in, typename Loader:
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) r[j] = in.template load_t<false>(min(s + j * SW + threadIdx.x, e - 1u));
   }
+  bool live[ITEMS];
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
     const uint32_t i = s + j * SW + threadIdx.x;
-    if (i < e) {
+    live[j] = i < e && !(skip && r[j].id == PT_NOIDX_U);
+    if (live[j]) {
       lb[j] = local_bin(bs, block_of_rec(gp, r[j]));
       rank[j] = atomicAdd(&binA[lb[j]], 1u);
     }
   }
   __syncthreads();
+  uint32_t cnt;                                   // records of the tile that are staged (all of them unless sentinels were dropped)
   {
     uint32_t c[BPT], sum = 0;
 #pragma unroll
     for (int i = 0; i < BPT; ++i) { c[i] = binA[threadIdx.x * BPT + i]; sum += c[i]; }
-    uint32_t tot;
-    uint32_t ex = block_excl_scan_n<SW / 64>(sum, wsum, tot);
+    uint32_t ex = block_excl_scan_n<SW / 64>(sum, wsum, cnt);
 #pragma unroll
     for (int i = 0; i < BPT; ++i) {
       const int b = threadIdx.x * BPT + i;
@@ -352,12 +360,9 @@ __global__ __launch_bounds__(SW) void scatter_kernel(Loader in, typename Loader:
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < ITEMS; ++j) {
-    const uint32_t i = s + j * SW + threadIdx.x;
-    if (i < e) stage[binA[lb[j]] + rank[j]] = r[j];
-  }
+  for (int j = 0; j < ITEMS; ++j)
+    if (live[j]) stage[binA[lb[j]] + rank[j]] = r[j];
   __syncthreads();
-  const uint32_t cnt = e - s;
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
     const uint32_t slot = j * SW + threadIdx.x;
@@ -542,16 +547,245 @@ __global__ __launch_bounds__(SW) void scatter_chunk_kernel(Loader in, typename L
   }
 }
 
+// ---- pass 1 WITHOUT a histogram pass (round 3): bin regions sized from a SAMPLE, space taken in blocks ----------------------------
+// The chunked pass 1 above reads the cloud twice: once for the per-chunk histograms that make its placement exact, once to move the
+// records (12 + 12 bytes per point read).  This form reads it once.  A sample of the cloud (one run of 256 points in 64) estimates
+// every bin's population; each bin gets a region of that size plus slack (8 sigma of the estimate + room for the padding below), laid
+// out back to back; PERSISTENT workgroups (one per CU) walk their share of the tiles and take space inside a bin's region in BLOCKS of
+// POOL_B records with one global atomic per block -- n / POOL_B reservations per address instead of one per tile -- filling a block
+// over as many tiles as it takes.  What a workgroup leaves unfilled in its last block of every bin at the end is padded with SENTINEL
+// records (id = PT_NOIDX_U, block id 0xFFFF: < 2 % of the records at 1e9 points), which pass 2 drops.  A bin that outgrows its region
+// (the sample missed a cluster) raises a flag: the records go to a scratch area, the host sees the flag in the read-back it makes
+// anyway and redoes the build with the exact histogram -- the same guess-and-verify shape as the sampled bounding box.
+constexpr uint32_t POOL_B = 128;                 // records per reservation block (2 KB of fp32 records)
+constexpr uint32_t POOL_SAMPLE_RUN = 256;        // consecutive points per sampled run (coalesced)
+struct PoolTables {
+  uint32_t* est;        // [PT_MAXBINS]  sample counts per bin
+  uint32_t* start;      // [PT_MAXBINS+1] region start of every bin (multiple of POOL_B)
+  uint32_t* cursor;     // [PT_MAXBINS]  next unreserved record of every bin's region; after pass 1: where the bin ends
+  uint32_t* limit;      // [PT_MAXBINS]  end of every bin's region
+  uint32_t* flag;       // [4] {overflow, sampled points, records incl. sentinels, -}
+};
+template <class Loader>
+__global__ __launch_bounds__(WG) void pool_sample_kernel(Loader in, GridParams gp, BinSpec bs, uint32_t n, uint32_t stride, PoolTables pt) {
+  __shared__ uint32_t hist[PT_MAXBINS];
+  for (int b = threadIdx.x; b < bs.nbins; b += WG) hist[b] = 0;
+  __syncthreads();
+  const uint64_t span = (uint64_t)stride * POOL_SAMPLE_RUN;
+  uint32_t mine = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * span + threadIdx.x; i < n; i += (uint64_t)gridDim.x * span) {
+    atomicAdd(&hist[local_bin(bs, block_of_rec(gp, in.load((uint32_t)i)))], 1u);
+    ++mine;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bs.nbins; b += WG) { const uint32_t c = hist[b]; if (c) atomicAdd(&pt.est[b], c); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&pt.flag[1], mine);
+}
+// regions from the sample: cap = n / ns * (s + 8 sqrt(s) + 32) + padding room, rounded up to whole blocks
+__global__ __launch_bounds__(WG) void pool_setup_kernel(PoolTables pt, int nbins, uint32_t n, uint32_t nwg, uint32_t pool_records /* capacity before the scratch area */) {
+  __shared__ uint32_t wsum[4];
+  const double f = pt.flag[1] ? (double)n / (double)pt.flag[1] : 1.0;
+  uint32_t cap[4], sum = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = threadIdx.x * 4 + i;
+    cap[i] = 0;
+    if (b < nbins) {
+      const double sct = (double)pt.est[b];
+      const double want = f * (sct + 8.0 * sqrt(sct) + 32.0) + (double)nwg * (double)POOL_B;
+      const double capd = fmin(want, 4.0e9);
+      cap[i] = (uint32_t)(((uint64_t)capd + POOL_B) / POOL_B * POOL_B);
+    }
+    sum += cap[i] / POOL_B;                       // (in blocks: the total may pass 2^32 records before it is refused)
+  }
+  uint32_t tot;
+  uint32_t ex = block_excl_scan(sum, wsum, tot);
+  const bool fits = (uint64_t)tot * POOL_B <= (uint64_t)pool_records;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = threadIdx.x * 4 + i;
+    if (b < nbins) {
+      // (regions that do not fit the allocation: every bin gets an empty region -- all of pass 1 lands in the scratch area, flagged)
+      const uint32_t st = fits ? ex * POOL_B : 0u;
+      pt.start[b] = st; pt.cursor[b] = st; pt.limit[b] = fits ? st + cap[i] : 0u;
+    }
+    ex += cap[i] / POOL_B;
+  }
+  if (threadIdx.x == 0) { pt.start[nbins] = fits ? tot * POOL_B : 0u; if (!fits) pt.flag[0] = 1u; }
+}
+template <class Loader, int ITEMS, int SW>
+__global__ __launch_bounds__(SW) void scatter_pool_kernel(Loader in, typename Loader::Rec* __restrict__ out, GridParams gp, BinSpec bs, uint32_t n,
+                                                          PoolTables pt, uint32_t scratch_base, uint16_t* __restrict__ bid, uint64_t* bbox6) {
+  using Rec = typename Loader::Rec;
+  constexpr uint32_t TILE = SW * ITEMS;
+  static_assert(PT_MAXBINS == SW, "one bin per thread in the reservation step");
+  static_assert(TILE % POOL_B == 0, "the scratch area holds one tile");
+  __shared__ uint32_t lpos[PT_MAXBINS];           // next free record of the block this workgroup is filling in every bin (0: none yet)
+  __shared__ uint32_t binA[PT_MAXBINS];           // counts, then local start of each bin in `stage`
+  __shared__ uint32_t thrS[PT_MAXBINS];           // stage slot at which the bin's share leaves the old block for the new one(s)
+  __shared__ uint32_t adjA[PT_MAXBINS];           // global position - stage slot, old block
+  __shared__ uint32_t adjB[PT_MAXBINS];           //                             , new block(s)
+  __shared__ uint32_t wsum[SW / 64];
+  __shared__ Rec stage[TILE];
+  __shared__ double wbox[SW / 64][6];
+  lpos[threadIdx.x] = 0;
+  const uint32_t ntiles = (uint32_t)(((uint64_t)n + TILE - 1) / TILE);
+  const uint32_t t0 = (uint32_t)((uint64_t)ntiles * blockIdx.x / gridDim.x), t1 = (uint32_t)((uint64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
+  using CT = decltype(in.load(0).x);
+  CT tmn[3] = {(CT)INFINITY, (CT)INFINITY, (CT)INFINITY}, tmx[3] = {(CT)-INFINITY, (CT)-INFINITY, (CT)-INFINITY};
+  bool nan_seen = false;
+  for (uint32_t t = t0; t < t1; ++t) {
+    const uint64_t s64 = (uint64_t)t * TILE;
+    const uint32_t s = (uint32_t)s64, e = (uint32_t)min((uint64_t)n, s64 + TILE);
+    binA[threadIdx.x] = 0;
+    __syncthreads();
+    Rec r[ITEMS];
+    uint32_t lb[ITEMS], rank[ITEMS];
+    if (in.has_ids()) {                                      // (workgroup-uniform; all of the tile's loads first: see scatter_chunk_kernel)
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) r[j] = in.template load_t<true>(min(s + j * SW + threadIdx.x, e - 1u));
+    } else {
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) r[j] = in.template load_t<false>(min(s + j * SW + threadIdx.x, e - 1u));
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const uint32_t i = s + j * SW + threadIdx.x;
+      if (i < e) {
+        lb[j] = local_bin(bs, block_of_rec(gp, r[j]));
+        rank[j] = atomicAdd(&binA[lb[j]], 1u);
+        if (bbox6) {                                           // the exact bounding box of everything read (the grid was laid out from a sample)
+          tmn[0] = r[j].x < tmn[0] ? r[j].x : tmn[0]; tmx[0] = r[j].x > tmx[0] ? r[j].x : tmx[0];
+          tmn[1] = r[j].y < tmn[1] ? r[j].y : tmn[1]; tmx[1] = r[j].y > tmx[1] ? r[j].y : tmx[1];
+          tmn[2] = r[j].z < tmn[2] ? r[j].z : tmn[2]; tmx[2] = r[j].z > tmx[2] ? r[j].z : tmx[2];
+          nan_seen |= (r[j].x != r[j].x) | (r[j].y != r[j].y) | (r[j].z != r[j].z);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const int b = threadIdx.x;
+      const uint32_t c = binA[b];
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan_n<SW / 64>(c, wsum, tot);
+      binA[b] = ex;
+      if (c) {
+        const uint32_t pos = lpos[b];
+        const uint32_t room = (POOL_B - (pos & (POOL_B - 1u))) & (POOL_B - 1u);      // left in the block being filled (regions start on block boundaries)
+        adjA[b] = pos - ex;
+        if (c <= room) { thrS[b] = ex + c; adjB[b] = 0u; lpos[b] = pos + c; }
+        else {
+          const uint32_t need = c - room, take = (need + POOL_B - 1u) / POOL_B * POOL_B;
+          const uint32_t base = atomicAdd(&pt.cursor[b], take);
+          thrS[b] = ex + room;
+          if (base > pt.limit[b] || take > pt.limit[b] - base) {      // the region is full: this share goes to the scratch area, the build is redone
+            atomicOr(&pt.flag[0], 1u);
+            adjB[b] = scratch_base - thrS[b];                          // (slot - thrS < TILE: inside the scratch area)
+            lpos[b] = pos + room;
+          } else {
+            adjB[b] = base - thrS[b];
+            lpos[b] = base + need;
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const uint32_t i = s + j * SW + threadIdx.x;
+      if (i < e) stage[binA[lb[j]] + rank[j]] = r[j];
+    }
+    __syncthreads();
+    const uint32_t cnt = e - s;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const uint32_t slot = j * SW + threadIdx.x;
+      if (slot < cnt) {
+        const Rec v = stage[slot];
+        const uint32_t blk = block_of_rec(gp, v);
+        const uint32_t lbn = local_bin(bs, blk);
+        const uint32_t pos = (slot < thrS[lbn] ? adjA[lbn] : adjB[lbn]) + slot;
+        out[pos] = v;
+        if (bid) bid[pos] = (uint16_t)(blk & (PT_MACRO_BLOCKS - 1));
+      }
+    }
+    __syncthreads();
+  }
+  // pad the blocks left partly filled: pass 2 reads every bin's region from its start to its cursor and drops these
+  {
+    const uint32_t pos = lpos[threadIdx.x];
+    const uint32_t room = (POOL_B - (pos & (POOL_B - 1u))) & (POOL_B - 1u);
+    if (room && pos + room <= pt.limit[threadIdx.x]) {
+      Rec sv;
+      sv.x = (decltype(sv.x))gp.bbmin[0]; sv.y = (decltype(sv.y))gp.bbmin[1]; sv.z = (decltype(sv.z))gp.bbmin[2]; sv.id = PT_NOIDX_U;
+      for (uint32_t q = 0; q < room; ++q) { out[pos + q] = sv; if (bid) bid[pos + q] = (uint16_t)0xFFFFu; }
+    }
+  }
+  if (bbox6) {
+    if (nan_seen) tmn[0] = (CT)-INFINITY;
+    double mn[3] = {(double)tmn[0], (double)tmn[1], (double)tmn[2]}, mx[3] = {(double)tmx[0], (double)tmx[1], (double)tmx[2]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { mn[a] = fmin(mn[a], __shfl_xor(mn[a], o)); mx[a] = fmax(mx[a], __shfl_xor(mx[a], o)); }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { wbox[threadIdx.x >> 6][a] = mn[a]; wbox[threadIdx.x >> 6][3 + a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      double v = wbox[0][threadIdx.x];
+      for (int w = 1; w < SW / 64; ++w) v = threadIdx.x < 3 ? fmin(v, wbox[w][threadIdx.x]) : fmax(v, wbox[w][threadIdx.x]);
+      if (threadIdx.x < 3) { if (v != INFINITY) atomicMin((unsigned long long*)&bbox6[threadIdx.x], (unsigned long long)enc_f64(v)); }
+      else if (v != -INFINITY) atomicMax((unsigned long long*)&bbox6[threadIdx.x], (unsigned long long)enc_f64(v));
+    }
+  }
+}
+// after pass 1: every bin ends at its cursor (clamped to its region); tiles of pass 2 per bin, scanned
+__global__ __launch_bounds__(WG) void pool_finish_kernel(PoolTables pt, int nbins, uint32_t tile_pts, uint32_t* counts, uint32_t* tile_first) {
+  __shared__ uint32_t wsum[4];
+  uint32_t t[4], st = 0, sc = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = threadIdx.x * 4 + i;
+    t[i] = 0;
+    if (b < nbins) {
+      const uint32_t end = min(pt.cursor[b], pt.limit[b]);
+      pt.cursor[b] = end;
+      const uint32_t c = end - pt.start[b];
+      counts[b] = c;
+      t[i] = (c + tile_pts - 1) / tile_pts;
+      sc += c;
+    }
+    st += t[i];
+  }
+  uint32_t tot, totc;
+  uint32_t et = block_excl_scan(st, wsum, tot);
+  __syncthreads();
+  (void)block_excl_scan(sc, wsum, totc);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = threadIdx.x * 4 + i;
+    if (b < nbins) tile_first[b] = et;
+    et += t[i];
+  }
+  if (threadIdx.x == 0) { tile_first[nbins] = tot; pt.flag[2] = totc; }
+}
+
 // pass-2 histogram from the block ids pass 1 left beside the records: same tiling and flush as hist_kernel
 template <int ITEMS>
 __global__ __launch_bounds__(WG) void hist_bid_kernel(const uint16_t* __restrict__ bid, int nbins, const uint32_t* __restrict__ seg_start,
-                                                      const uint32_t* __restrict__ tile_first, int nseg, uint32_t* counts, int tiles_per_wg) {
+                                                      const uint32_t* __restrict__ tile_first, int nseg, uint32_t* counts, int tiles_per_wg,
+                                                      const uint32_t* __restrict__ seg_end = nullptr) {
   __shared__ uint32_t hist[PT_MACRO_BLOCKS];
   constexpr uint32_t TILE = WG * ITEMS;
   int cur_seg = -1;
   for (int tt = 0; tt < tiles_per_wg; ++tt) {
     uint32_t seg, s, e;
-    if (!tile_range(seg_start, tile_first, nseg, blockIdx.x * tiles_per_wg + tt, TILE, seg, s, e)) break;
+    if (!tile_range(seg_start, tile_first, nseg, blockIdx.x * tiles_per_wg + tt, TILE, seg, s, e, seg_end)) break;
     if ((int)seg != cur_seg) {
       __syncthreads();
       if (cur_seg >= 0)
@@ -580,7 +814,7 @@ __global__ __launch_bounds__(WG) void hist_bid_kernel(const uint16_t* __restrict
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const uint32_t i = g + (uint32_t)q, id = (w[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu;
-          if (i >= s && i < e) atomicAdd(&hist[id], 1u);
+          if (i >= s && i < e && id < (uint32_t)PT_MACRO_BLOCKS) atomicAdd(&hist[id], 1u);      // (0xFFFF: a sentinel of the pooled pass 1)
         }
       }
     }
@@ -731,6 +965,16 @@ int pt_sort_chunk_tiles(uint32_t n, size_t rec_size) {
   const uint32_t ntiles = (n + tile - 1) / tile;
   return (int)std::max<uint32_t>(1, std::min<uint32_t>(32, ntiles / 4096));
 }
+// The pooled pass 1's capacity.  Regions: cap_b <= f (s_b + 8 sqrt(s_b) + 32) + (nwg + 1) B with f = n / ns and sum(s_b) = ns, and
+// sum(sqrt(s_b)) <= sqrt(nbins ns) whatever the distribution; plus 2 % and the scratch area of one tile.
+uint64_t pt_sort_pool_records(uint32_t n, uint32_t nbins, uint32_t nwg, size_t rec_size) {
+  if (!n || !nbins) return 0;
+  const double f = 64.0, ns = std::max(1.0, (double)n / f);
+  const double regions = (double)n + f * (8.0 * std::sqrt((double)nbins * ns) + 32.0 * nbins) + (double)nbins * ((double)nwg + 1.0) * POOL_B;
+  const uint64_t tile1 = (uint64_t)1024 * (rec_size == 16 ? 8 : 4);
+  const uint64_t total = (uint64_t)(regions * 1.02) + 4096 + tile1;
+  return total < 0xFFFFFF00ull ? total : 0;                    // (positions are 32-bit)
+}
 uint32_t pt_sort_num_chunks(uint32_t n, size_t rec_size) {
   const uint32_t tile = (uint32_t)pt_sort_tile_points(rec_size);
   const uint32_t ntiles = (n + tile - 1) / tile, ct = (uint32_t)pt_sort_chunk_tiles(n, rec_size);
@@ -863,6 +1107,40 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
   }
   // two levels: planar -> out_final (by macro block) -> tmp (by block) -> out_final (by cell)
   const BinSpec b1{0, 9, (int)nmacro};
+  if (tb.pool_records && n) {
+    // pass 1 without its histogram pass: regions from a sample, blocks, sentinels (scatter_pool_kernel); pass 2 reads every bin from its
+    // region's start to where pass 1 stopped (seg_end) and drops the sentinels
+    constexpr uint32_t TILE1 = 1024 * ITEMS_S;
+    const PoolTables pt{tb.pool_est, tb.start1, tb.cursor1, tb.pool_limit, tb.pool_flag};
+    ck(hipMemsetAsync(tb.pool_est, 0, sizeof(uint32_t) * PT_MAXBINS, s));
+    ck(hipMemsetAsync(tb.pool_flag, 0, sizeof(uint32_t) * 4, s));
+    const uint32_t stride = 64;                                       // one run of 256 points in 64: what pt_sort_pool_records assumes
+    const uint64_t runs = ((uint64_t)n + POOL_SAMPLE_RUN - 1) / POOL_SAMPLE_RUN;
+    const uint32_t gs = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((runs + stride - 1) / stride, 1), 1024);
+    hipLaunchKernelGGL((pool_sample_kernel<PlanarLoader<T>>), dim3(gs), dim3(WG), 0, s, pl, gp, b1, n, stride, pt);
+    const uint32_t scratch = (uint32_t)(tb.pool_records - TILE1);
+    hipLaunchKernelGGL(pool_setup_kernel, dim3(1), dim3(WG), 0, s, pt, (int)nmacro, n, tb.pool_nwg, scratch);
+    mark(1);
+    const uint32_t nt1 = (uint32_t)(((uint64_t)n + TILE1 - 1) / TILE1);
+    hipLaunchKernelGGL((scatter_pool_kernel<PlanarLoader<T>, ITEMS_S, 1024>), dim3(std::min(tb.pool_nwg, nt1)), dim3(1024), 0, s, pl, out_final, gp, b1, n, pt,
+                       scratch, tb.bid, bbox6_verify);
+    hipLaunchKernelGGL(pool_finish_kernel, dim3(1), dim3(WG), 0, s, pt, (int)nmacro, TILE, tb.counts1, tb.tile_first2);
+    mark(2);
+    RecLoader<Rec> rl{out_final};
+    const uint32_t ntiles2 = (uint32_t)(((uint64_t)n + (uint64_t)nmacro * tb.pool_nwg * POOL_B) / TILE) + nmacro + 1;
+    const int tpw = 4;
+    hipLaunchKernelGGL((hist_bid_kernel<ITEMS>), dim3((ntiles2 + tpw - 1) / tpw), dim3(WG), 0, s, tb.bid, (int)PT_MACRO_BLOCKS, tb.start1,
+                       tb.tile_first2, (int)nmacro, tb.block_count, tpw, tb.cursor1);
+    pt_launch_scan_u32(tb.block_count, tb.block_start, nblocks + 1, tb.scan_tmp, s);
+    ck(hipMemcpyAsync(tb.cursor2, tb.block_start, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s));
+    mark(3);
+    hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS_S, SW>), dim3(ntiles2), dim3(SW), 0, s, rl, tmp, gp, b2, tb.start1, tb.tile_first2,
+                       (int)nmacro, tb.cursor2, tb.cursor1);
+    mark(4);
+    if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start, tb.occupied, tb.shadow32);
+    mark(5);
+    return done(do_finalize ? out_final : tmp);
+  }
   const int chunk_tiles = pt_sort_chunk_tiles(n, sizeof(Rec));
   const uint32_t nchunks = n ? (ntiles + chunk_tiles - 1) / chunk_tiles : 0;
   const uint32_t ngroups = (nchunks + COL_GROUP - 1) / COL_GROUP;

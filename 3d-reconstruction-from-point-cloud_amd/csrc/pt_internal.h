@@ -25,6 +25,13 @@ struct SortTables {
   uint32_t* startM;      //   the scatter cursors and the tile table of the last partition pass (segments = macro blocks)
   uint32_t* cursorM;
   uint32_t* tile_firstM;
+  // pooled pass 1 (two-level sorts of big clouds; pool_records == 0: the exact, histogram-first pass 1): bin regions sized from a
+  // sample with slack between them, space taken in blocks, sentinel padding that pass 2 drops (pt_grid.hip, scatter_pool_kernel)
+  uint32_t* pool_est;    // [PT_MAXBINS]  sample counts
+  uint32_t* pool_limit;  // [PT_MAXBINS]  end of every bin's region
+  uint32_t* pool_flag;   // [4] {a region overflowed, points sampled, records incl. sentinels after pass 1, -}
+  uint64_t pool_records; // capacity (records) of the pass-1 output and of `bid`, scratch area of one tile at its end included
+  uint32_t pool_nwg;     // persistent workgroups of the pooled pass 1 (one per CU)
   hipError_t* status;    // optional: receives the first HIP error of the sort's launch path (hipSuccess otherwise)
   hipEvent_t* ev;        // optional [6]: start, after hist1, scatter1, hist2+scan, scatter2, finalize (null = no timing)
 };
@@ -46,6 +53,9 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
                                uint64_t* bbox6_verify = nullptr);   // two-level sorts: pass 1's histogram also reduces the exact bbox into it
 void pt_launch_sum_u32(const uint32_t* v, uint32_t n, uint32_t* out, hipStream_t s);   // finalize's block words: out[0] += non-empty cells, out[1] = max(fullest cell)
 int pt_sort_tile_points(size_t rec_size);
+// capacity (records) the pooled pass 1 needs for n points in nbins bins with nwg persistent workgroups: the regions' worst case
+// for ANY distribution of the sample over the bins, plus the scratch area; 0 = the cloud is not pooled (too small, too large)
+uint64_t pt_sort_pool_records(uint32_t n, uint32_t nbins, uint32_t nwg, size_t rec_size);
 // grids of more than PT_MAXBINS macro blocks: pass 1 partitions by GROUPS of 2^shift macro blocks (at most PT_MAXBINS groups)
 inline int pt_sort_group_shift(uint32_t nblocks) {
   const uint32_t nm = nblocks / PT_MACRO_BLOCKS;

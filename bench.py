@@ -48,7 +48,7 @@ def survey_alg_bytes(name, n, m, k, s=12):
     build and which is split here over its data-moving passes in proportion to the bytes each must move."""
     if name == "knn_query":
         return n * s + m * s + m * k * 16 + m * (4 * k + 24)
-    share = {"bbox_reduce": 0.0, "pass1_histogram": 12, "pass1_scatter": 28, "pass2_histogram_scan": 2, "pass2_scatter": 32, "finalize_cellsort": 32}
+    share = {"bbox_reduce": 0.0, "pass1_histogram": 0.2, "pass1_scatter": 28, "pass2_histogram_scan": 2, "pass2_scatter": 32, "finalize_cellsort": 32}
     if name in share:
         return n * (2 * s + 4) * share[name] / sum(share.values())
     return m * (2 * s + 4)            # target_sort: the same formula over the targets
@@ -61,7 +61,7 @@ def kernel_alg_bytes(name, n, m, k, s=12):
     rec = s + 4
     return {
         "bbox_reduce": n * s,
-        "pass1_histogram": n * s,
+        "pass1_histogram": n * s // 64,        # (the pooled pass 1 reads a 1/64 sample; the exact pass 1 of smaller clouds reads n * s)
         "pass1_scatter": n * (s + rec),
         "pass2_histogram_scan": n * rec,
         "pass2_scatter": n * 2 * rec,
@@ -72,7 +72,9 @@ def kernel_alg_bytes(name, n, m, k, s=12):
     }[name]
 
 
-PMC_KERNEL = {"bbox_reduce": "bbox_kernel", "pass1_histogram": "hist_chunk_kernel", "pass1_scatter": "scatter_chunk_kernel",
+# (since round 3 big clouds run the pooled pass 1: pool_sample_kernel instead of the histogram pass, scatter_pool_kernel instead of
+#  scatter_chunk_kernel; the traffic summary is looked up under either name)
+PMC_KERNEL = {"bbox_reduce": "bbox_kernel", "pass1_histogram": ("pool_sample_kernel", "hist_chunk_kernel"), "pass1_scatter": ("scatter_pool_kernel", "scatter_chunk_kernel"),
               "pass2_histogram_scan": "hist_bid_kernel", "pass2_scatter": "scatter_kernel", "finalize_cellsort": "finalize_kernel",
               "knn_query": "knn_tile_kernel"}
 
@@ -98,8 +100,12 @@ def pmc_traffic(kernel, workload, world):
         return None
     if kernel == "__step__":
         return prof.get("step", {}).get("hbm_bytes")
-    rec = prof["kernels"].get(PMC_KERNEL.get(kernel, ""))
-    return rec["hbm_bytes"] if rec else None
+    names = PMC_KERNEL.get(kernel, "")
+    for name in (names if isinstance(names, tuple) else (names,)):
+        rec = prof["kernels"].get(name)
+        if rec:
+            return rec["hbm_bytes"]
+    return None
 
 
 def cpu_baseline(n_total, m_total, k, seed):
@@ -141,8 +147,11 @@ class BoxSampler:
     def __init__(self, torch, index):
         import glob
         self.dir = self.hwmon = None
+        self.props = {}
         try:
             pr = torch.cuda.get_device_properties(index)
+            self.props = {"name": pr.name, "arch": getattr(pr, "gcnArchName", None), "compute_units": pr.multi_processor_count,
+                          "l2_bytes": getattr(pr, "L2_cache_size", None), "hbm_bytes": pr.total_memory}
             want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
             for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
                 if "-" in os.path.basename(card):
@@ -174,15 +183,15 @@ class BoxSampler:
 
     def static(self):
         if not self.dir:
-            return {"card": None}
+            return dict(self.props, card=None)
         level = lambda f: next((l.split(":")[1].strip().rstrip("*").strip() for l in (self._rd(os.path.join(self.dir, f)) or "").splitlines() if l.endswith("*")), None)
-        return {"card": os.path.basename(os.path.dirname(self.dir)), "pci": os.path.basename(os.path.realpath(self.dir)),
+        return dict(self.props, **{"card": os.path.basename(os.path.dirname(self.dir)), "pci": os.path.basename(os.path.realpath(self.dir)),
                 "compute_partition": self._rd(os.path.join(self.dir, "current_compute_partition")),
                 "memory_partition": self._rd(os.path.join(self.dir, "current_memory_partition")),
                 "perf_level": self._rd(os.path.join(self.dir, "power_dpm_force_performance_level")),
                 "sclk_levels": (self._rd(os.path.join(self.dir, "pp_dpm_sclk")) or "").replace("\n", " | "),
                 "mclk_mhz": level("pp_dpm_mclk"), "fclk_mhz": level("pp_dpm_fclk"),
-                "power_cap_w": self._num(self.hwmon, "power1_cap", 1e-6), "vbios": self._rd(os.path.join(self.dir, "vbios_version"))}
+                "power_cap_w": self._num(self.hwmon, "power1_cap", 1e-6), "vbios": self._rd(os.path.join(self.dir, "vbios_version"))})
 
     def _one(self):
         return (self._num(self.hwmon, "freq1_input", 1e-6), self._num(self.hwmon, "power1_input", 1e-6), self._num(self.hwmon, "temp2_input", 1e-3),

@@ -92,6 +92,9 @@ typedef struct pt_stats_t {
   int32_t refine_levels;    /* ... and how many levels deep (<= 3) */
   uint32_t max_cell_points; /* points of the fullest grid cell of the last build (adaptive builds) */
   uint32_t n_wave;          /* last query: targets answered by the one-wave-per-target kernel (dense neighbourhoods) */
+  int32_t pass1_pooled;     /* last build: 1 pass 1 took its bin regions from a sample (no histogram pass: big clouds, two-level sort);
+                             * -1 a bin outgrew its sampled region and the build was redone with the exact pass 1; 0 exact pass 1 */
+  int32_t _pad2;
 } pt_stats_t;
 
 /* ---- context ------------------------------------------------------------------------ */
@@ -109,6 +112,9 @@ int  pt_set_stream(pt_ctx*, void* hip_stream);
  * group kernel for its leftovers with the geometry chosen from the cell density (default), 2 / 3 = force the small /
  * large tile geometry), "guess_min_points" (clouds at least this large lay their grid out from the bounding box of a
  * sample and verify it during the first partition pass instead of spending a pass on the exact box; default 8 Mi),
+ * "pool_min_points" (clouds at least this large, on the two-level sort, size the bins of the first partition pass from a sample
+ * instead of a histogram pass over the whole cloud -- with slack, and a flag that sends the build back to the exact histogram when a
+ * bin outgrows its estimate; default 32 Mi, 0 = never),
  * "refine_threshold" (grid cells holding more points than this get an 8x8x8 sub-grid, recursively up to three levels, which
  * searches descend into instead of scanning the cell end to end -- clouds with strong density contrast; default 8192, 0 = never),
  * "wave_min" (on such clouds a target whose 27 nearest cells hold at least this many points is answered by a whole wave instead of

@@ -629,7 +629,67 @@ def test_even_chunk_scatter_variant_against_oracle(pkg, oracle):
     tgt = oracle.synth_xyz(seed, 1, m)
     with pkg.PointsTransfer(device=0, k_hint=k) as p:
         p.build(src)
+        assert p.stats()["pass1_pooled"] == 1          # (from 32 Mi points up pass 1 sizes its bins from a sample: no histogram pass)
         idx, d2 = p.query(tgt, k)
+        p.set_param("pool_min_points", 0)              # the exact, histogram-first pass 1 on the same cloud
+        p.rebuild()
+        assert p.stats()["pass1_pooled"] == 0
+        idx0, d20 = p.query(tgt, k)
+    wi, wd = oracle.KdTree(src).query(tgt, k)
+    assert np.array_equal(idx, wi) and np.array_equal(d2, wd)
+    assert np.array_equal(idx0, wi) and np.array_equal(d20, wd)
+
+
+@pytest.mark.parametrize("f64,slab", [(False, False), (True, False), (False, True)])
+def test_pooled_pass1_on_small_clouds(pkg, oracle, f64, slab):
+    """The pooled pass 1 (bin regions from a sample, space taken in blocks, sentinel padding dropped by pass 2) forced onto clouds the
+    oracle answers in seconds: fp32, fp64 (32-byte records) and a slab with caller-given global indices; blobs make the bins uneven."""
+    rng = np.random.default_rng(77)
+    n, m, k = 3_000_000, 4000, 8
+    src = rng.random((3, n))
+    src[:, : n // 3] = 0.5 + 0.02 * rng.standard_normal((3, n // 3))            # a third of the cloud in one blob
+    src = np.clip(src, 0.0, 1.0)
+    src = src if f64 else src.astype(np.float32)
+    tgt = src[:, rng.integers(0, n, m)] + (1e-4 * rng.standard_normal((3, m))).astype(src.dtype)
+    gidx = rng.permutation(n).astype(np.uint32) if slab else None
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.set_param("pool_min_points", 1)
+        p.build(src, gidx=gidx)
+        st = p.stats()
+        assert st["n_levels"] == 2 and st["pass1_pooled"] == 1, st
+        idx, d2 = p.query(tgt, k)
+        p.rebuild()                                                             # and again from the remembered grid
+        assert p.stats()["pass1_pooled"] == 1
+        idx2, d22 = p.query(tgt, k)
+    wi, wd = oracle.KdTree(src.astype(np.float64)).query(tgt.astype(np.float64), k)
+    if slab:
+        wi = np.where(wi == pkg.NOIDX, wi, gidx[np.minimum(wi, n - 1)])
+        order = np.lexsort((wi, wd), axis=1)                                    # ties are broken by the GLOBAL index
+        wi = np.take_along_axis(wi, order, 1); wd = np.take_along_axis(wd, order, 1)
+    assert np.array_equal(idx, wi) and np.array_equal(d2, wd)
+    assert np.array_equal(idx2, wi) and np.array_equal(d22, wd)
+
+
+def test_pooled_pass1_overflow_falls_back_to_the_exact_histogram(pkg, oracle):
+    """A cloud built to fool the sample: the runs the sample reads (one run of 256 points in 64) are uniform, every other point sits in
+    one small clump.  The clump's bin outgrows the region its sample gave it, the flag is raised, and the build is redone with the
+    exact pass 1 -- same answer as the oracle, and the context stops pooling for this cloud."""
+    rng = np.random.default_rng(5)
+    n, m, k = 3_000_000, 3000, 8
+    src = rng.random((3, n), dtype=np.float32)
+    run = np.arange(n) // 256
+    hidden = (run % 64) != 0
+    src[:, hidden] = (0.25 + 0.01 * rng.random((3, int(hidden.sum())))).astype(np.float32)
+    tgt = np.concatenate([rng.random((3, m // 2), dtype=np.float32), (0.25 + 0.01 * rng.random((3, m - m // 2))).astype(np.float32)], axis=1)
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.set_param("pool_min_points", 1)
+        p.set_param("adaptive", 0)                         # (keep the coarse grid of the bounding box: the clump stays in one macro bin)
+        p.build(src)
+        st = p.stats()
+        assert st["pass1_pooled"] == -1, st
+        idx, d2 = p.query(tgt, k)
+        p.rebuild()
+        assert p.stats()["pass1_pooled"] == 0              # no more pooling for this cloud
     wi, wd = oracle.KdTree(src).query(tgt, k)
     assert np.array_equal(idx, wi) and np.array_equal(d2, wd)
 
