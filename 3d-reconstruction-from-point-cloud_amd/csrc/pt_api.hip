@@ -61,6 +61,8 @@ struct pt_ctx {
   bool has_gidx = false, has_attr = false, built = false, posattr_valid = false;
   uint64_t guess_min_points = 8u << 20;   // clouds at least this large lay their grid out from a sampled bounding box
   bool bbox_guess_ok = true;   // big clouds: lay the grid out from a sampled bounding box (cleared when a guess failed; reset by an upload)
+  bool stream_bounds = true;   // pt_stream_query: later chunks are searched under the targets' current k-th distances and skipped when out of reach ("stream_bounds", a measurement switch)
+  bool tile_bounds = false;    // run_query: bounds come with every target of the set (the tile kernel's bounded variant may take them)
   bool pool_ok = true;         // big clouds, two-level sorts: pass 1 without its histogram pass (cleared when a bin outgrew its sampled region; reset by an upload)
   uint64_t pool_min_points = 32u << 20;   // ... from this size up ("pool_min_points"; 0 switches the pooled pass 1 off)
   int n_cu = 256;              // compute units of the device: persistent workgroups of the pooled pass 1
@@ -537,7 +539,10 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
   //  and would prune -- or keep -- everything; such clouds are answered by the group kernel, which prunes in fp64)
   const double h2d = c->gp.h * c->gp.h;
   const bool h2_ok = h2d <= 3.0e38 && h2d >= 1.2e-38;
-  const bool use_tile = c->tile && !contrast && !bound2_dev && m && k <= PT_TILE_MAX_K && h2_ok && (ttype == PT_F32 || c->rec32_valid);
+  // radius-bounded queries run the group kernel (few targets, scattered: the slab exchange) -- unless the caller says the bounds come with
+  // EVERY target of a block-sorted set (pt_stream_query from its second chunk on): then the tile kernel's bounded variant takes them
+  const bool tile_bounded = bound2_dev && c->tile_bounds && ttype == PT_F32 && !br && k <= 24;
+  const bool use_tile = c->tile && !contrast && (!bound2_dev || tile_bounded) && m && k <= PT_TILE_MAX_K && h2_ok && (ttype == PT_F32 || c->rec32_valid);
   // The tile kernel over all blocks (+ the large geometry for the blocks the small one had to pass on); what it cannot
   // settle is on the todo list afterwards.  fp64 clouds: the LDS image is the fp32 shadow of the sorted records, the exact
   // 32-byte records are fetched for the few candidates that reach the ranking pass.
@@ -555,14 +560,14 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     }
     pt_launch_knn_tile(c->gp, src32, (const uint32_t*)c->cell_start.p, tgt32, c->ttb.block_start, k, idx_dev, d2_dev, (uint32_t*)c->todo.p, todo_n,
                        tile_small, battr, (uint32_t)c->n_total, br ? br->mode : 0, br ? br->rgb_out : nullptr, br ? br->nrm_out : nullptr, nullptr, 0,
-                       second_chance ? (uint32_t*)c->retry.p : nullptr, retry_n, src64, tgt64, c->e_src, c->stream);
+                       second_chance ? (uint32_t*)c->retry.p : nullptr, retry_n, src64, tgt64, c->e_src, c->stream, bound2_dev);
     if (second_chance) {
       HIPCHK(c, hipMemcpyAsync(c->h_counter + 5, retry_n, 4, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));            // (one short read-back; usually 0 blocks and no launch)
       if (c->h_counter[5])
         pt_launch_knn_tile(c->gp, src32, (const uint32_t*)c->cell_start.p, tgt32, c->ttb.block_start, k, idx_dev, d2_dev, (uint32_t*)c->todo.p, todo_n,
                            0, battr, (uint32_t)c->n_total, br ? br->mode : 0, br ? br->rgb_out : nullptr, br ? br->nrm_out : nullptr,
-                           (const uint32_t*)c->retry.p, c->h_counter[5], nullptr, nullptr, src64, tgt64, c->e_src, c->stream);
+                           (const uint32_t*)c->retry.p, c->h_counter[5], nullptr, nullptr, src64, tgt64, c->e_src, c->stream, bound2_dev);
     }
     return PT_OK;
   };
@@ -687,7 +692,7 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (use_tile) {
       { int r = tile_launches((const RecF*)c->rec.p, tsorted, nullptr, nullptr, todo_n); if (r != PT_OK) return r; }
-      group_f32(tsorted, nullptr, (const uint32_t*)c->todo.p, todo_n);
+      group_f32(tsorted, bound2_dev, (const uint32_t*)c->todo.p, todo_n);       // (what the tile kernel left over keeps its bound, if it came with one)
       if (br && !wave_blended)   // the targets the tile kernel handed over get their blend from the lists the group kernel just wrote
         pt_launch_blend_list<RecF>((const uint32_t*)c->todo.p, todo_n, m, tsorted, idx_dev, d2_dev, k, br->mode, (const Attr*)c->attr.p,
                                    (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
@@ -849,6 +854,7 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!strcmp(name, "wave_force")) { c->wave_force = value != 0; return PT_OK; }
   if (!strcmp(name, "wave_min")) { if (!(value >= 0 && value <= 4e9)) return fail(c, PT_ERR_ARG, "wave_min out of range"); c->wave_min = (uint32_t)value; return PT_OK; }
   if (!strcmp(name, "refine_threshold")) { if (!(value >= 0 && value <= 1e9)) return fail(c, PT_ERR_ARG, "refine_threshold out of range"); c->refine_threshold = value; return PT_OK; }
+  if (!strcmp(name, "stream_bounds")) { c->stream_bounds = value != 0; return PT_OK; }
   if (!strcmp(name, "pool_min_points")) { c->pool_min_points = value < 0 ? 0 : (uint64_t)value; c->pool_ok = true; return PT_OK; }   // pooled pass 1 from this size up (0: never)
   if (!strcmp(name, "guess_min_points")) { c->guess_min_points = value < 1 ? 1 : (uint64_t)value; return PT_OK; }   // sampled-bbox builds from this size up   // 0 group kernel only, 1 auto, 2 small tiles, 3 large tiles
   if (!strcmp(name, "own_stream")) { if (value != 0) c->stream = c->own_stream; return PT_OK; }
@@ -1387,7 +1393,8 @@ int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64
   const uint64_t m = c->m;
   const size_t ts = tsize(xyz_type), lists = std::max<uint64_t>(m, 1) * (size_t)k;
   const uint64_t nchunks = n ? (n + chunk_points - 1) / chunk_points : 0;
-  DevBuf best_i[2], best_d[2], ci, cd, stage[2];
+  DevBuf best_i[2], best_d[2], ci, cd, stage[2], sbound, sfirst;
+  uint64_t skipped = 0, revisited = 0;
   hipStream_t copy_stream = nullptr;
   hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
   const int sync_save = c->sync;
@@ -1397,7 +1404,8 @@ int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64
     c->in_xyz = keep_in;
     c->in_half = keep_half; c->xyz32_valid = false;
     c->sync = sync_save;
-    DevBuf* all[] = {&best_i[0], &best_i[1], &best_d[0], &best_d[1], &ci, &cd, &stage[0], &stage[1]};
+    c->tile_bounds = false;
+    DevBuf* all[] = {&best_i[0], &best_i[1], &best_d[0], &best_d[1], &ci, &cd, &stage[0], &stage[1], &sbound, &sfirst};
     for (DevBuf* b : all) release(c, *b);
     for (auto& e : copied) if (e) (void)hipEventDestroy(e);
     for (auto& e : consumed) if (e) (void)hipEventDestroy(e);
@@ -1405,7 +1413,7 @@ int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64
   };
   auto run = [&]() -> int {
     for (int b = 0; b < 2; ++b) { RES(c, best_i[b], lists * 8); RES(c, best_d[b], lists * 8); }
-    RES(c, ci, lists * 4); RES(c, cd, lists * 8);
+    RES(c, ci, lists * 4); RES(c, cd, lists * 8); RES(c, sbound, std::max<uint64_t>(m, 1) * 8);
     HIPCHK(c, hipMemsetAsync(best_i[0].p, 0xFF, lists * 8, c->stream));                          // ~0 = no neighbour yet
     HIPCHK(c, hipMemsetAsync(best_d[0].p, 0x7F, lists * 8, c->stream));    // (never compared: the merge reads a distance only beside a valid id)
     HIPCHK(c, hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
@@ -1414,8 +1422,10 @@ int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64
       HIPCHK(c, hipEventCreateWithFlags(&copied[b], hipEventDisableTiming));
       HIPCHK(c, hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
     }
+    uint64_t held[2] = {~0ull, ~0ull};               // which chunk each stage buffer holds
     auto upload = [&](uint64_t ch) -> int {          // chunk ch -> stage[ch & 1], planar with the chunk's own length as the stride
       const int b = (int)(ch & 1);
+      held[b] = ch;
       const uint64_t f0 = ch * chunk_points, cnt = std::min<uint64_t>(chunk_points, n - f0);
       HIPCHK(c, hipStreamWaitEvent(copy_stream, consumed[b], 0));      // (a never-recorded event does not block)
       for (int a = 0; a < 3; ++a)
@@ -1425,22 +1435,89 @@ int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64
     };
     c->sync = 1;
     int cur = 0;
-    if (nchunks) { int r = upload(0); if (r) return r; }
-    for (uint64_t ch = 0; ch < nchunks; ++ch) {
-      const int b = (int)(ch & 1);
+    RES(c, sfirst, std::max<uint64_t>(m, 1) * 4);
+    {   // first[t] = nchunks: not searched in any chunk yet
+      std::vector<uint32_t> init((size_t)std::max<uint64_t>(m, 1), (uint32_t)nchunks);
+      HIPCHK(c, hipMemcpyAsync(sfirst.p, init.data(), init.size() * 4, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    std::vector<double> boxes((size_t)nchunks * 6), margins((size_t)nchunks, 0.0);
+    uint32_t* cnt_dev = (uint32_t*)c->counter.p + 6;
+    // one (chunk, sweep): stage[b] holds chunk ch -- exact bounding box (forward sweep; remembered for the backward one), the bounds the
+    // targets bring and how many of them reach the box at all, then build + search + merge unless nobody does
+    auto adopt = [&](uint64_t ch, int b) {
       const uint64_t f0 = ch * chunk_points, cnt = std::min<uint64_t>(chunk_points, n - f0);
-      if (ch + 1 < nchunks) { int r = upload(ch + 1); if (r) return r; }          // the next chunk travels while this one is searched
-      HIPCHK(c, hipStreamWaitEvent(c->stream, copied[b], 0));
       c->in_xyz = stage[b];
       c->src_type = xyz_type; c->n = cnt; c->n_total = cnt; c->has_gidx = false; c->has_attr = false; c->built = false;
       c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
+    };
+    auto bounds_and_reach = [&](uint64_t ch, int backward, uint32_t& reach) -> int {
+      const double* mn = &boxes[(size_t)ch * 6];
+      HIPCHK(c, hipMemsetAsync(cnt_dev, 0, 4, c->stream));
+      if (xyz_type == PT_F32) pt_launch_stream_sweep<float>((const float*)c->t_xyz.p, (const unsigned long long*)best_i[cur].p, (const double*)best_d[cur].p, (uint32_t)m, k, (uint32_t)ch,
+                                                            backward, (uint32_t*)sfirst.p, mn, mn + 3, margins[(size_t)ch], (double*)sbound.p, cnt_dev, c->stream);
+      else pt_launch_stream_sweep<double>((const double*)c->t_xyz.p, (const unsigned long long*)best_i[cur].p, (const double*)best_d[cur].p, (uint32_t)m, k, (uint32_t)ch,
+                                          backward, (uint32_t*)sfirst.p, mn, mn + 3, margins[(size_t)ch], (double*)sbound.p, cnt_dev, c->stream);
+      HIPCHK(c, hipMemcpyAsync(c->h_counter + 6, cnt_dev, 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      reach = c->h_counter[6];
+      return PT_OK;
+    };
+    auto search_and_merge = [&](uint64_t ch, int b) -> int {
+      const uint64_t f0 = ch * chunk_points;
       { int r = rebuild(c); if (r) return r; }
       HIPCHK(c, hipEventRecord(consumed[b], c->stream));               // the build no longer reads stage[b] (records hold the coordinates)
-      { int r = run_query(c, c->t_xyz.p, c->tgt_type, m, k, nullptr, (uint32_t*)ci.p, (double*)cd.p); if (r) return r; }
+      c->tile_bounds = true;
+      { int r = run_query(c, c->t_xyz.p, c->tgt_type, m, k, (const double*)sbound.p, (uint32_t*)ci.p, (double*)cd.p); c->tile_bounds = false; if (r) return r; }
       pt_launch_merge_stream((const unsigned long long*)best_i[cur].p, (const double*)best_d[cur].p, (const uint32_t*)ci.p, (const double*)cd.p,
                              (unsigned long long)(first_id + f0), (uint32_t)m, k, (unsigned long long*)best_i[cur ^ 1].p, (double*)best_d[cur ^ 1].p, c->stream);
       HIPCHK(c, hipGetLastError());
       cur ^= 1;
+      return PT_OK;
+    };
+    // ---- forward sweep: every chunk travels once, the next one while this one is searched ----
+    if (nchunks) { int r = upload(0); if (r) return r; }
+    for (uint64_t ch = 0; ch < nchunks; ++ch) {
+      const int b = (int)(ch & 1);
+      if (ch + 1 < nchunks) { int r = upload(ch + 1); if (r) return r; }          // the next chunk travels while this one is searched
+      HIPCHK(c, hipStreamWaitEvent(c->stream, copied[b], 0));
+      adopt(ch, b);
+      double mn[3], mx[3];
+      { int r = source_bbox(c, 1u, mn, mx); if (r) return r; }                      // exact box: 12 bytes per point, against a build and a search
+      for (int a = 0; a < 3; ++a) { boxes[(size_t)ch * 6 + a] = mn[a]; boxes[(size_t)ch * 6 + 3 + a] = mx[a]; }
+      {   // "inside" is taken with a margin of two point spacings times the cube root of k: the chunk's own density says over what distance a
+          // target just outside its box still finds its neighbours here (and an unbounded search from that far outside costs a ring or two)
+        double ext[3], big = 0.0, vol = 1.0;
+        for (int a = 0; a < 3; ++a) { ext[a] = mx[a] - mn[a]; big = std::max(big, ext[a]); }
+        for (int a = 0; a < 3; ++a) vol *= std::max(ext[a], big * 1e-3);
+        const uint64_t cntc = std::min<uint64_t>(chunk_points, n - ch * chunk_points);
+        margins[(size_t)ch] = big > 0.0 ? 2.0 * std::cbrt(vol / (double)std::max<uint64_t>(cntc, 1)) * std::cbrt((double)k) : 0.0;
+      }
+      uint32_t reach = (uint32_t)m;
+      if (m && c->stream_bounds) { int r = bounds_and_reach(ch, 0, reach); if (r) return r; }
+      else if (m) {     // measurement switch: round 2's behaviour -- every target, unbounded, in every chunk
+        std::vector<double> inf((size_t)m, std::numeric_limits<double>::infinity());
+        HIPCHK(c, hipMemcpyAsync(sbound.p, inf.data(), (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+      }
+      if (m && reach == 0) { HIPCHK(c, hipEventRecord(consumed[b], c->stream)); ++skipped; continue; }    // nobody can gain anything from this chunk now
+      { int r = search_and_merge(ch, b); if (r) return r; }
+    }
+    // ---- backward sweep: the deferred (target, chunk) pairs -- targets that lay outside a chunk's box before they had a list.  None for a
+    //      cloud whose chunks each cover the whole volume (every target is inside every box); for a cloud in spatial order the targets near
+    //      the border of their own slab bring the earlier chunks back, one upload each, and only those ----
+    if (m && c->stream_bounds) {
+      for (uint64_t ch = nchunks; ch-- > 0;) {
+        uint32_t reach = 0;
+        { int r = bounds_and_reach(ch, 1, reach); if (r) return r; }
+        if (!reach) continue;
+        const int b = (int)(ch & 1);
+        if (held[b] != ch) { int r = upload(ch); if (r) return r; }               // (the last two chunks of the forward sweep are still in the stage buffers)
+        HIPCHK(c, hipStreamWaitEvent(c->stream, copied[b], 0));
+        adopt(ch, b);
+        { int r = search_and_merge(ch, b); if (r) return r; }
+        ++revisited;
+      }
     }
     if (m) {
       HIPCHK(c, hipMemcpyAsync(idx64_out, best_i[cur].p, (size_t)m * k * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1453,6 +1530,8 @@ int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64
   };
   const int r = run();
   cleanup();
+  c->st.stream_skipped = (int32_t)std::min<uint64_t>(skipped, 0x7FFFFFFF);
+  c->st.stream_revisited = (int32_t)std::min<uint64_t>(revisited, 0x7FFFFFFF);
   // the chunks are gone with the stage buffers: no source cloud is resident any more (a later query needs a pt_build_* first)
   c->n = 0; c->n_total = 0; c->built = false; c->src_type = -1; c->has_attr = false;
   return r;

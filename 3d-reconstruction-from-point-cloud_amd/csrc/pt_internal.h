@@ -92,13 +92,16 @@ constexpr int PT_TILE_MAX_K = 32;      // beyond this the group kernel answers e
 void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* cell_start, const RecF* tgt, const uint32_t* tblock_start,
                         int k, uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int geometry, const Attr* attr, uint32_t n_attr,
                         int mode, float* rgb_out, float* nrm_out, const uint32_t* blocks, uint32_t nblocks_listed, uint32_t* retry,
-                        uint32_t* retry_n, const RecD* src_exact, const RecD* tgt_exact, float e_src, hipStream_t s);
+                        uint32_t* retry_n, const RecD* src_exact, const RecD* tgt_exact, float e_src, hipStream_t s, const double* bound = nullptr);
 template <class T>
 void pt_launch_request_pack(const T* x, const T* y, const T* z, const double* d2, uint32_t m, int k, int axis, const double* bounds_dev, int g,
                             int my_slab, uint32_t* count, uint32_t* sel, double* pkt, hipStream_t s);
 void pt_launch_merge(const uint32_t* idx_lists, const double* d2_lists, int g, uint32_t m, int k, uint32_t* idx_out,
                      double* d2_out, hipStream_t s);
 // streamed sources: merge the running best lists (u64 ids) with one chunk's lists (chunk-local u32 ids + base), out of place
+template <class T>
+void pt_launch_stream_sweep(const T* xyz_planar, const unsigned long long* best_idx, const double* best_d2, uint32_t m, int k, uint32_t chunk, int backward,
+                            uint32_t* first, const double lo[3], const double hi[3], double margin, double* bound, uint32_t* count, hipStream_t s);
 void pt_launch_merge_stream(const unsigned long long* best_idx, const double* best_d2, const uint32_t* chunk_idx, const double* chunk_d2,
                             unsigned long long base, uint32_t m, int k, unsigned long long* out_idx, double* out_d2, hipStream_t s);
 template <class T>

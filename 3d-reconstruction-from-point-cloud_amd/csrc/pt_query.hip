@@ -384,7 +384,13 @@ __global__ __launch_bounds__(WG, HIER ? (KPL == 4 ? 3 : 4) : 1) void knn_kernel(
     T.c[a] = (int)fmin(fmax(T.u[a], 0.0), (double)(gp.dim[a] - 1));
   }
   TopList<KPL> top;
-  top.init(L, k, bound2 ? bound2[tr.id] : INFINITY);
+  const double bnd0 = bound2 ? bound2[tr.id] : INFINITY;
+  if (bnd0 < 0.0) {            // a negative bound: this target wants nothing from this cloud (pt_stream_query's "not this chunk") -- group-uniform
+    const size_t row0 = (size_t)tr.id * (size_t)k;
+    for (int e = L; e < k; e += GL) { out_idx[row0 + e] = PT_NOIDX_U; if (out_d2) out_d2[row0 + e] = INFINITY; }
+    return;
+  }
+  top.init(L, k, bnd0);
   const int c0 = T.c[0], c1 = T.c[1], c2 = T.c[2];
   Pending pend{&pend_lds[HIER ? (threadIdx.x / GL) * PEND_CAP : 0], 0u, HIER ? ha.thr : 0xFFFFFFFFu};
   Pending* const pp = HIER ? &pend : nullptr;
@@ -1020,6 +1026,10 @@ __global__ __launch_bounds__(WG, HIER ? PT_WV_MINW_H : PT_WV_MINW) void knn_wave
     c[a] = (int)fmin(fmax(W.u[a], 0.0), (double)(gp.dim[a] - 1));
   }
   W.bnd_d = bound2 ? bound2[tr.id] : INFINITY;
+  if (W.bnd_d < 0.0) {         // (as in knn_kernel: nothing wanted from this cloud; wave-uniform)
+    if (lane < k) { const size_t row0 = (size_t)tr.id * (size_t)k; out_idx[row0 + lane] = PT_NOIDX_U; if (out_d2) out_d2[row0 + lane] = INFINITY; }
+    return;
+  }
   W.reset();
   auto cgap = [&](int a, int lo, int hi) -> double {        // as TargetGeom::gap
     return fmax(fmax((double)lo - W.u[a], W.u[a] - (double)(hi + 1)) - PT_CELL_EPS, 0.0);
@@ -1250,7 +1260,11 @@ __device__ inline void glds16(const uint4* g, uint4* lbase) {
 struct TileBlend { const Attr* attr; uint32_t n_attr; int mode; float* rgb_out; float* nrm_out; };
 // Second chance for blocks whose region is over this geometry's LDS budget but within the large geometry's: their ids go
 // to `retry` (retry != null), and a second launch (blocks != null: blockIdx.x indexes that list) takes them.
-struct TileBlocks { const uint32_t* blocks; uint32_t* retry; uint32_t* retry_n; uint32_t retry_cap; };
+struct TileBlocks { const uint32_t* blocks; uint32_t* retry; uint32_t* retry_n; uint32_t retry_cap; const double* bound; };
+// BND (fp32 clouds, no fused blend): every target brings a radius bound[id] -- the k-th squared distance it already has from another
+// part of the cloud (the chunks of a streamed source, pt_stream_query) -- and only points with d2 <= bound matter.  The bound joins
+// pass 1's own (whichever is smaller prunes pass 2), settles targets whose k-th neighbour lies beyond ring 1 when the bound does not,
+// and lets targets with fewer than k points in reach finish with a short list (the rest NOIDX / +inf, as a bounded query returns).
 // fp64 clouds (DBL): the LDS image and the two fp32 passes work on fp32-ROUNDED coordinates (the build's shadow records,
 // whose id field is the sorted position), under a bound widened by the rounding; pass 3 fetches the exact 32-byte
 // records of the queued candidates by position.  src / tgt: the exact records; e_src: largest |coordinate| rounding
@@ -1260,7 +1274,7 @@ struct TileDouble { const RecD* src; const RecD* tgt; float e_src; };
 // KC: length of pass 1's per-lane value chain (<= K).  The merges and the ranking run at width K (a power of two); a chain of KC
 // entries leaves l32[KC..K) at +inf, which is all a query with k <= KC needs: the reference's K = 20 runs the K = 32 body with
 // a 24-deep chain (three quarters of pass 1's per-candidate work).
-template <int K, int TILE_CAP, int TWG, bool WIDE = false, bool BLEND = false, bool DBL = false, int KC = K>
+template <int K, int TILE_CAP, int TWG, bool WIDE = false, bool BLEND = false, bool DBL = false, int KC = K, bool BND = false>
 __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(GridParams gp, const RecF* __restrict__ src, const uint32_t* __restrict__ cs,
                                                         const RecF* __restrict__ tgt, const uint32_t* __restrict__ tblock_start, int k,
                                                         uint32_t* __restrict__ out_idx, double* __restrict__ out_d2,
@@ -1480,6 +1494,12 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
     //      bound is +inf, the queue overflows and the target goes to the todo list.)  Per-lane lists shorter than K would
     //      still be valid but loosen the bound: measured 3.7 % of the targets overflow the queue with 3K/4, 17 % with K/2. ----
     const int sx = (u[0] - (double)cc[0]) >= 0.5 ? 0 : -1, sy = (u[1] - (double)cc[1]) >= 0.5 ? 0 : -1, sz = (u[2] - (double)cc[2]) >= 0.5 ? 0 : -1;
+    double bnd = INFINITY;
+    if constexpr (BND) {
+      static_assert(!DBL && !BLEND, "the bounded variant is built for fp32 clouds without the fused blend");
+      if (active) bnd = tb.bound[tr.id];
+    }
+    const bool scan1 = active && !(BND && bnd < 0.0);      // (a negative bound -- "nothing from this cloud" -- skips pass 1 too; pass 2 prunes itself)
     float l32[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) l32[j] = INFINITY;
@@ -1495,7 +1515,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
       for (int o = 0; o < 4; ++o) {                    // all eight table reads in flight together
         const int c = cbase + ((sz + (o >> 1)) * TILE_R + (sy + (o & 1))) * TILE_R + 1 + sx;
         ps[o] = (uint32_t)lstart[c] + ql;
-        pe[o] = active ? (uint32_t)lstart[c + 2] : 0u;
+        pe[o] = scan1 ? (uint32_t)lstart[c + 2] : 0u;
       }
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
@@ -1523,6 +1543,10 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
       for (int j = 1; j < K; ++j) kv = (j == k - 1) ? l32[j] : kv;
     }
     float thr = kth_bound32(kv);
+    if constexpr (BND) {
+      // a candidate with exact d2 <= bnd has d32 <= bnd (1 + 2^-21): the bound rounded UP to fp32, times 1 + 2^-20
+      thr = bnd < 0.0 ? -1.f : fminf(thr, __double2float_ru(bnd) * 1.000001f + 1e-30f);
+    }
     if constexpr (DBL) {
       // Rounded coordinates move every difference by at most E per axis (source + target rounding), i.e. every distance
       // by at most sqrt(3) E: k candidates lie within sqrt(kv') + sqrt(3) E of the target, so the true top k do, and
@@ -1659,7 +1683,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
       if (hi < gp.dim[a] - 1) { covered = false; dout = fmin(dout, (double)(hi + 1) - u[a]); }
     }
     dout = fmax(dout - PT_CELL_EPS, 0.0);
-    const bool done = !overflow && (covered || dout * dout * h2 > kd);
+    const bool done = !overflow && (covered || dout * dout * h2 > (BND ? fmin(kd, bnd) : kd));
     if (active) {
       if (done) {
         const size_t row = (size_t)tr.id * (size_t)k;
@@ -1973,11 +1997,27 @@ template void pt_launch_knn_wave<RecD>(const GridParams&, const RecD*, const uin
 void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* cell_start, const RecF* tgt, const uint32_t* tblock_start, int k,
                         uint32_t* out_idx, double* out_d2, uint32_t* todo, uint32_t* todo_n, int geometry, const Attr* attr, uint32_t n_attr, int mode,
                         float* rgb_out, float* nrm_out, const uint32_t* blocks, uint32_t nblocks_listed, uint32_t* retry, uint32_t* retry_n,
-                        const RecD* src_exact, const RecD* tgt_exact, float e_src, hipStream_t s) {
+                        const RecD* src_exact, const RecD* tgt_exact, float e_src, hipStream_t s, const double* bound) {
   const uint32_t nb = blocks ? nblocks_listed : (uint32_t)gp.nblocks;
   if (!nb) return;
   const TileBlend bl{attr, n_attr, mode, rgb_out, nrm_out};
-  const TileBlocks tbk{blocks, retry, retry_n, (uint32_t)PT_TILE_CAP_LARGE};
+  const TileBlocks tbk{blocks, retry, retry_n, (uint32_t)PT_TILE_CAP_LARGE, bound};
+  if (bound) {                                       // bounded variant: fp32 clouds, no fused blend, k <= 24 (pt_api.hip only sends those here)
+#define PT_TILE_LAUNCHB(KK, CAP, TH, KCH)                                                                                                                 \
+  hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH, false, false, false, KCH, true>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, \
+                     out_idx, out_d2, todo, todo_n, bl, tbk, TileDouble{nullptr, nullptr, 0.f})
+    if (geometry == 1 && k <= 16) {
+      if (k <= 8) PT_TILE_LAUNCHB(8, PT_TILE_CAP_SMALL_8, 512, 8);
+      else PT_TILE_LAUNCHB(16, PT_TILE_CAP_SMALL_16, 512, 16);
+    } else {
+      if (k <= 8) PT_TILE_LAUNCHB(8, PT_TILE_CAP_LARGE, 768, 8);
+      else if (k <= 16) PT_TILE_LAUNCHB(16, PT_TILE_CAP_LARGE, 768, 16);
+      else if (k <= 20) PT_TILE_LAUNCHB(32, PT_TILE_CAP_LARGE, 768, 20);
+      else PT_TILE_LAUNCHB(32, PT_TILE_CAP_LARGE, 768, 24);
+    }
+#undef PT_TILE_LAUNCHB
+    return;
+  }
   const TileDouble dd{src_exact, tgt_exact, e_src};
 #define PT_TILE_LAUNCH1(KK, CAP, TH, WD, BL, DB, KCH)                                                                                             \
   hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH, WD, BL, DB, KCH>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, out_idx, \
@@ -2002,6 +2042,8 @@ void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* c
     if (k <= 8) PT_TILE_LAUNCH(8, PT_TILE_CAP_LARGE, 768, false);
     else if (k <= 16) PT_TILE_LAUNCH(16, PT_TILE_CAP_LARGE, 768, false);
     else if (k <= 20) PT_TILE_LAUNCHC(32, PT_TILE_CAP_LARGE, 768, false, 20);       // the reference's K = 20 (src/pointsTransfer.cpp:128): a chain of exactly 20
+    // (round 3: the same body on 1024 threads -- 16 waves per CU, 128 VGPRs with 56 bytes of spills, 7680-record region -- measured 6.77 ms
+    //  against 6.74 at 100M / 10M: more waves of one workgroup do not shorten its latency chain)
     else if (k <= 24) PT_TILE_LAUNCHC(32, PT_TILE_CAP_LARGE, 768, false, 24);
     else PT_TILE_LAUNCH(32, PT_TILE_CAP_LARGE, 768, false);
   }
@@ -2010,6 +2052,56 @@ void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* c
 #undef PT_TILE_LAUNCH1
 }
 
+// pt_stream_query, once per chunk and sweep: the bound every target brings to this chunk's search, and how many targets bring one that
+// reaches the chunk's bounding box at all (box distance: Distance::min_distance_to_rectangle of the reference, src/Distance.h:27-57;
+// `<=` because an equal distance could still enter the list).
+//   forward sweep, chunk c:   a target searched in an earlier chunk (first[t] < c) brings its current k-th squared distance (+inf while
+//                             its list is short); one that has not been searched yet and lies INSIDE the chunk's box -- or within
+//                             `margin` of it, a few point spacings: the distance over which its neighbours may well be in this chunk and
+//                             an unbounded search from outside costs a ring or two -- is searched unbounded from now on (first[t] = c);
+//                             one that lies farther outside and has no list yet is DEFERRED (-1: the
+//                             kernels return an empty list for it) -- searching it from outside, unbounded, is the slow path of every
+//                             kernel, and the chunk that holds its neighbourhood is still to come;
+//   backward sweep, chunk c:  exactly the deferred pairs, first[t] > c, now with a bound.  Every (target, chunk) pair is searched once,
+//                             under a bound that is an upper bound of the target's final k-th distance, so the merged lists are the
+//                             resident search's.
+template <class T>
+__global__ __launch_bounds__(WG) void stream_sweep_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z,
+                                                          const unsigned long long* __restrict__ bi, const double* __restrict__ bd, uint32_t m, int k,
+                                                          uint32_t c, int backward, uint32_t* __restrict__ first, double lx, double ly, double lz, double hx,
+                                                          double hy, double hz, double margin2, double* __restrict__ bound, uint32_t* count) {
+  const uint32_t t = blockIdx.x * WG + threadIdx.x;
+  bool reach = false;
+  if (t < m) {
+    const double q[3] = {(double)x[t], (double)y[t], (double)z[t]}, lo[3] = {lx, ly, lz}, hi[3] = {hx, hy, hz};
+    double d = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { const double g = q[a] < lo[a] ? lo[a] - q[a] : (q[a] > hi[a] ? q[a] - hi[a] : 0.0); d += g * g; }
+    const size_t last = (size_t)t * (size_t)k + (size_t)(k - 1);
+    const double kth = bi[last] != ~0ull ? bd[last] : INFINITY;
+    const uint32_t f = first[t];
+    double b;
+    if (d != d) b = -1.0;                                       // a NaN coordinate: no neighbours anywhere, the row stays empty
+    else if (backward) b = f > c ? kth : -1.0;
+    else if (f < c) b = kth;
+    else if (d <= margin2) { b = INFINITY; first[t] = c; }      // inside the box, or within a few point spacings of it
+    else b = -1.0;
+    bound[t] = b;
+    reach = b >= 0.0 && !(d > b);
+  }
+  const uint32_t n = (uint32_t)__popcll(__ballot(reach));
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(count, n);
+}
+template <class T>
+void pt_launch_stream_sweep(const T* xyz_planar, const unsigned long long* best_idx, const double* best_d2, uint32_t m, int k, uint32_t chunk, int backward,
+                            uint32_t* first, const double lo[3], const double hi[3], double margin, double* bound, uint32_t* count, hipStream_t s) {
+  if (m) hipLaunchKernelGGL(stream_sweep_kernel<T>, dim3((m + WG - 1) / WG), dim3(WG), 0, s, xyz_planar, xyz_planar + m, xyz_planar + 2 * (size_t)m, best_idx, best_d2,
+                            m, k, chunk, backward, first, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], margin * margin, bound, count);
+}
+template void pt_launch_stream_sweep<float>(const float*, const unsigned long long*, const double*, uint32_t, int, uint32_t, int, uint32_t*, const double*, const double*,
+                                            double, double*, uint32_t*, hipStream_t);
+template void pt_launch_stream_sweep<double>(const double*, const unsigned long long*, const double*, uint32_t, int, uint32_t, int, uint32_t*, const double*, const double*,
+                                             double, double*, uint32_t*, hipStream_t);
 void pt_launch_merge_stream(const unsigned long long* best_idx, const double* best_d2, const uint32_t* chunk_idx, const double* chunk_d2,
                            unsigned long long base, uint32_t m, int k, unsigned long long* out_idx, double* out_d2, hipStream_t s) {
   if (!m) return;

@@ -18,6 +18,7 @@
 //   --pad K          edge-padding kernel, default 25 (0 = none)
 //   --neighbors FILE also dump the neighbour indices (binary u32[M][K])
 //   --ply-threads T  parser threads for the two input files (default 0 = one per hardware thread; host/ply_fast.h)
+//   --json FILE      phase times (the stdout lines' seconds) and the library's device times / grid statistics as one JSON object
 //   --gpus N         the cloud cut into N spatial slabs, one process per GPU, slab exchange over RCCL (host/sharded.h)
 // There is no CPU path: without a usable GPU the tool reports the error and exits non-zero.
 #include <chrono>
@@ -105,6 +106,7 @@ int main(int argc, char** argv) {
   const std::string pc_file_name = argv[1], mesh_file_name = argv[2];
   int K = 20, device = 0, mode = PT_BLEND_MEAN, ply_threads = 0, resolution = 8192, pad = 25;     // K, RESOLUTION: reference :128-129; 25: :594
   std::string out_name = "transfer.ply", nbr_name, tex_name = "texture.png";                      // texture.png: reference :615
+  std::string json_name;                           // --json FILE: the phase times of the stdout lines + pt_stats as one JSON object
   int gpus = 0, rank = -1;
   bool finalize = false;
   std::string rendezvous;
@@ -118,6 +120,7 @@ int main(int argc, char** argv) {
     else if (a == "--out") out_name = val();
     else if (a == "--neighbors") nbr_name = val();
     else if (a == "--texture") tex_name = val();
+    else if (a == "--json") json_name = val();
     else if (a == "--resolution") resolution = std::atoi(val());
     else if (a == "--pad") pad = std::atoi(val());
     else if (a == "--gpus") { gpus = std::atoi(val()); continue; }                 // (not handed on: the launcher adds it itself)
@@ -189,7 +192,8 @@ int main(int argc, char** argv) {
     return 0;   // the reference returns 0 here (:140)
   }
   std::cout << "PC Point count: " << point_count << std::endl;
-  std::cout << "Read point set in: " << since(t_task) << " seconds" << std::endl;
+  const double t_read_cloud = since(t_task);
+  std::cout << "Read point set in: " << t_read_cloud << " seconds" << std::endl;
   t_task = clk::now();
 
   if (cloud.n == 0) rc = pt_upload_begin(ctx, 0, PT_F64, 1);            // header-only / empty file: an empty cloud
@@ -197,7 +201,8 @@ int main(int argc, char** argv) {
   if (rc == PT_OK) rc = pt_upload_end(ctx);
   free_pinned();
   if (rc != PT_OK) { std::cerr << "pointsTransfer: build failed: " << pt_last_error(ctx) << std::endl; pt_ctx_destroy(ctx); return 1; }
-  std::cout << "Built Kd tree in: " << since(t_task) << " seconds" << std::endl;   // the line's wording is the contract
+  const double t_build = since(t_task);
+  std::cout << "Built Kd tree in: " << t_build << " seconds" << std::endl;   // the line's wording is the contract
   t_task = clk::now();
 
   ply::FastMesh mesh;
@@ -208,7 +213,8 @@ int main(int argc, char** argv) {
   }
   std::cout << "Mesh vertex count: " << mesh.vertex_count << std::endl;
   std::cout << "Mesh face count: " << mesh.face_count << std::endl;
-  std::cout << "Read mesh faces: " << since(t_task) << " seconds" << std::endl;
+  const double t_read_mesh = since(t_task);
+  std::cout << "Read mesh faces: " << t_read_mesh << " seconds" << std::endl;
   t_task = clk::now();
 
   const size_t M = mesh.vertices.size();
@@ -246,10 +252,28 @@ int main(int argc, char** argv) {
     std::ofstream o(nbr_name, std::ios::binary);
     o.write(reinterpret_cast<const char*>(idx.data()), (std::streamsize)(idx.size() * sizeof(uint32_t)));
   }
-  std::cout << "Output time: " << since(t_task) << " seconds" << std::endl;
-  std::cout << "Total real time: " << since(t_total) << " seconds" << std::endl;
+  const double t_output = since(t_task), t_all = since(t_total);
+  std::cout << "Output time: " << t_output << " seconds" << std::endl;
+  std::cout << "Total real time: " << t_all << " seconds" << std::endl;
 
   pt_stats_t st;
+  if (!json_name.empty() && pt_stats(ctx, &st) == PT_OK) {
+    // one object: what the stdout lines say (wall seconds per phase, the reference's :255-:619) and the library's own device times
+    std::ofstream j(json_name);
+    j.precision(9);
+    j << "{\"cloud\": \"" << pc_file_name << "\", \"mesh\": \"" << mesh_file_name << "\", \"k\": " << K << ", \"points\": " << point_count << ", \"points_read\": " << cloud.n
+      << ", \"mesh_vertices\": " << mesh.vertex_count << ", \"mesh_faces\": " << mesh.face_count << ", \"resolution\": " << resolution
+      << ",\n \"seconds\": {\"read_cloud\": " << t_read_cloud << ", \"build\": " << t_build << ", \"read_mesh\": " << t_read_mesh << ", \"search\": " << t_search
+      << ", \"blend\": " << t_blend << ", \"bake\": " << t_bake << ", \"output\": " << t_output << ", \"total\": " << t_all << "}"
+      << ",\n \"pt_stats\": {\"n_source\": " << st.n_source << ", \"n_target\": " << st.n_target << ", \"ms_build\": " << st.ms_build << ", \"ms_sort_targets\": " << st.ms_sort_targets
+      << ", \"ms_query\": " << st.ms_query << ", \"ms_blend\": " << st.ms_blend << ", \"ms_bake\": " << st.ms_bake << ", \"grid_dim\": [" << st.grid_dim[0] << ", " << st.grid_dim[1] << ", "
+      << st.grid_dim[2] << "], \"cell_size\": " << st.cell_size << ", \"n_cells\": " << st.n_cells << ", \"n_levels\": " << st.n_levels << ", \"rho_occupied\": " << st.rho_occupied
+      << ", \"n_refine\": " << st.n_refine << ", \"bbox_guess\": " << st.bbox_guess << ", \"pass1_pooled\": " << st.pass1_pooled << ", \"n_nodes\": " << st.n_nodes
+      << ", \"n_leftover\": " << st.n_leftover << ", \"n_wave\": " << st.n_wave << ", \"device_bytes\": " << st.device_bytes << ", \"ms_kernel\": [";
+    for (int i = 0; i < 8; ++i) j << (i ? ", " : "") << st.ms_kernel[i];
+    j << "]}}\n";
+    if (!j) std::cerr << "pointsTransfer: cannot write " << json_name << std::endl;
+  }
   if (pt_stats(ctx, &st) == PT_OK)
     std::cerr << "[pt_hip] grid " << st.grid_dim[0] << "x" << st.grid_dim[1] << "x" << st.grid_dim[2] << " cells, build " << st.ms_build
               << " ms, target sort " << st.ms_sort_targets << " ms, kNN " << st.ms_query << " ms, blend " << st.ms_blend << " ms, texture bake " << st.ms_bake << " ms (device time)"

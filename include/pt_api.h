@@ -94,6 +94,8 @@ typedef struct pt_stats_t {
   uint32_t n_wave;          /* last query: targets answered by the one-wave-per-target kernel (dense neighbourhoods) */
   int32_t pass1_pooled;     /* last build: 1 pass 1 took its bin regions from a sample (no histogram pass: big clouds, two-level sort);
                              * -1 a bin outgrew its sampled region and the build was redone with the exact pass 1; 0 exact pass 1 */
+  int32_t stream_skipped;   /* last pt_stream_query: (chunk, forward sweep) steps it did not search because no target's bound reached the chunk's box */
+  int32_t stream_revisited; /* ... and chunks its backward sweep brought back for targets that lay outside them before they had a list */
   int32_t _pad2;
 } pt_stats_t;
 
@@ -290,7 +292,13 @@ int   pt_upload_end(pt_ctx*);
  * `xyz` in page-locked memory, pt_host_alloc, for that overlap), gridded and searched like a resident cloud, and the k best
  * of the chunk are merged into the running k best under the same total order (d2, index).  Indices are 64-bit -- a streamed
  * cloud may hold more than 2^32 points -- and are `first_id` + the point's position in `xyz`.  The result is bit-identical to
- * a resident search of the whole cloud.  xyz: planar, n points of xyz_type (PT_F32 / PT_F64; the targets' type);
+ * a resident search of the whole cloud.  Every target brings a bound to every chunk: its current k-th squared distance once it has a
+ * list; nothing (an unbounded search) in the first chunk whose bounding box contains it; and "not now" for chunks it lies outside of
+ * before it has a list -- those (target, chunk) pairs are taken up by a second, backward sweep, under a bound by then.  A chunk that
+ * no target's bound reaches is not searched (forward sweep) or not even uploaded again (backward sweep): a cloud stored in spatial
+ * order -- what scanners and tiled exports deliver -- costs each target its own neighbourhood's chunks, a cloud in random order costs
+ * what it did before (every chunk covers everything: no pair is ever deferred, the backward sweep uploads nothing).
+ * xyz: planar, n points of xyz_type (PT_F32 / PT_F64; the targets' type);
  * idx64_out / d2_out: host, [m][k].  Afterwards NO source cloud is resident in the context (the chunks lived in the stage
  * buffers): a later pt_query_* needs a pt_build_* first and fails with PT_ERR_STATE otherwise. */
 int  pt_stream_query(pt_ctx*, const void* xyz, int xyz_type, uint64_t n, uint64_t chunk_points, uint64_t first_id, int k,

@@ -114,7 +114,7 @@ def test_metric_has_no_fma_in_query_kernels():
         b = b.split("; -- End function")[0]
         if "s_endpgm" not in b:
             continue
-        if "knn_tile_kernel" in name and re.search(r"ELb1ELb[01]ELi\d+EEEv", name):       # <..., WIDE, BLEND = true, DBL, KC>
+        if "knn_tile_kernel" in name and re.search(r"ELb1ELb[01]ELi\d+ELb[01]EEEv", name):       # <..., WIDE, BLEND = true, DBL, KC, BND>
             continue
         checked += 1
         assert "v_fma_f64" not in b and "v_fmac_f64" not in b, name
@@ -131,8 +131,12 @@ def test_metric_has_no_fma_in_query_kernels():
         hier = ("knn_kernel" in name or "knn_wave_kernel" in name) and re.search(r"ELb1EEEv", name) is not None
         wave = "knn_wave_kernel" in name
         touches = re.search(r"\tscratch_(load|store)|\tbuffer_(load|store)_dword[^\n]*offen|\tbuffer_(load|store)_dword[^\n]*s\[0:3\]", b) is not None
-        # (a frame reserved for SGPR spills that end up in VGPR lanes shows as ScratchSize without a single scratch instruction: not traffic)
-        assert int(m.group(1)) == 0 or not touches or (hier and int(m.group(1)) <= 512) or (wave and int(m.group(1)) <= 64), (name, m.group(1))
+        # The rule is ScratchSize == 0.  One more exception, shown by the ISA itself: a kernel whose SGPRs spill into the LANES of a VGPR
+        # (`v_writelane_b32` / `v_readlane_b32`, marked "SGPR spill to VGPR lane" by the compiler) gets a small frame reserved for that
+        # VGPR and never touches it -- no scratch_* / buffer_* instruction in the body: register moves, not memory traffic (the fused
+        # k-NN + blend tile kernel: 36 bytes, 16 lane writes at entry).
+        lane_spill_only = (not touches) and int(m.group(1)) <= 64 and "SGPR spill to VGPR lane" in b
+        assert int(m.group(1)) == 0 or lane_spill_only or (hier and int(m.group(1)) <= 512) or (wave and int(m.group(1)) <= 64), (name, m.group(1))
 
 
 def test_png_writer_roundtrip(tmp_path):

@@ -256,9 +256,13 @@ def test_cli_end_to_end(tmp_path, pkg, oracle):
         f.write("3 0 1 2\n3 2 1 3\n")
     exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "pointsTransfer")
     nb = tmp_path / "nn.bin"
-    r = subprocess.run([exe, str(pc), str(mesh), "--neighbors", str(nb), "--out", str(tmp_path / "out.ply"), "--resolution", "256"],
+    r = subprocess.run([exe, str(pc), str(mesh), "--neighbors", str(nb), "--out", str(tmp_path / "out.ply"), "--resolution", "256", "--json", str(tmp_path / "run.json")],
                        capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 0, r.stderr
+    import json
+    rep = json.load(open(tmp_path / "run.json"))                            # --json: the stdout lines' seconds + pt_stats
+    assert rep["k"] == k and rep["points"] == n and rep["mesh_vertices"] == m and rep["pt_stats"]["n_source"] == n
+    assert set(rep["seconds"]) == {"read_cloud", "build", "read_mesh", "search", "blend", "bake", "output", "total"} and len(rep["pt_stats"]["ms_kernel"]) == 8
     assert os.path.getsize(tmp_path / "texture.png") > 100                 # the reference's artefact, in the working directory (:615)
     lines = [l.split(":")[0] for l in r.stdout.strip().splitlines()]
     assert lines == ["PC Point count", "Read point set in", "Built Kd tree in", "Mesh vertex count", "Mesh face count", "Read mesh faces",
@@ -1108,6 +1112,66 @@ def test_streamed_source_equals_resident(pkg, oracle, dtype, nchunks):
         assert (ei == np.uint64(0xFFFFFFFFFFFFFFFF)).all() and np.isinf(ed).all()
     ri, rd = oracle.knn_bruteforce(src.astype(np.float64), tgt.astype(np.float64), k)
     assert np.array_equal(wi, ri) and np.array_equal(wd, rd)
+
+
+@pytest.mark.parametrize("dtype,k", [(np.float32, 8), (np.float32, 20), (np.float64, 8)])
+def test_streamed_source_in_spatial_order_skips_chunks(pkg, oracle, dtype, k):
+    """A cloud stored in spatial order (sorted along x, as scanners and tiled exports deliver it): from the second chunk on the
+    targets' current k-th distances bound the search, chunks no target can reach are skipped (pt_stats.stream_skipped), and the
+    answer stays the resident search's, bit for bit -- targets far outside the cloud and in its gaps included."""
+    rng = np.random.default_rng(57)
+    n, m = 400_000, 6000
+    src = rng.random((3, n))
+    src[0] = np.sort(src[0] * 8.0)                                          # eight unit cubes side by side, in x order
+    src[:, 100_000:100_300] = src[:, 99_700:100_000]                        # duplicates across a chunk border
+    src = src.astype(dtype)
+    tgt = rng.random((3, m)); tgt[0] = tgt[0] * 0.9                         # all targets near the first chunks ...
+    tgt[:, :50] += 20.0                                                     # ... except a few far outside the cloud (they reach everything)
+    tgt = tgt.astype(dtype)
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.build(src)
+        wi, wd = p.query(tgt, k)
+        far = np.zeros(m, bool); far[:50] = True
+        p.set_targets(tgt[:, ~far])
+        gi, gd = p.stream_query(src, n // 8, k)
+        assert p.stats()["stream_skipped"] >= 5                              # chunks 2 .. 7 lie beyond every near target's k-th distance
+        assert np.array_equal(gi, wi[~far].astype(np.uint64)) and np.array_equal(gd, wd[~far])
+        assert p.stats()["stream_revisited"] == 0                            # every target lay inside the first chunk's box: nothing deferred
+        p.set_targets(tgt)                                                   # the far targets lie outside EVERY chunk: deferred by the forward sweep,
+        gi, gd = p.stream_query(src, n // 8, k)                              # picked up -- unbounded, from outside -- by the backward sweep's first chunk
+        st = p.stats()
+        assert st["stream_skipped"] >= 5 and 1 <= st["stream_revisited"] <= 2, st
+        assert np.array_equal(gi, wi.astype(np.uint64)) and np.array_equal(gd, wd)
+        # targets spread over the whole cloud: each is searched first in its own slab's chunk, the ones near a slab's lower border bring
+        # the chunk before it back
+        wide = tgt[:, 50:].copy(); wide[0] = (rng.random(m - 50) * 8.0).astype(dtype)     # (without the far ones: those reach every slab alike)
+        p.build(src); ui, ud = p.query(wide, k)
+        p.set_targets(wide)
+        gi, gd = p.stream_query(src, n // 8, k)
+        st = p.stats()
+        assert np.array_equal(gi, ui.astype(np.uint64)) and np.array_equal(gd, ud)
+        assert st["stream_revisited"] <= 2, st                                # (targets within a few point spacings of a slab were served by it in the forward sweep)
+    ri, rd = oracle.knn_bruteforce(src.astype(np.float64)[:, :], tgt.astype(np.float64)[:, 50:250], k)
+    assert np.array_equal(wi[50:250], ri) and np.array_equal(wd[50:250], rd)
+
+
+def test_streamed_source_100m_equals_resident(pkg, oracle):
+    """the streamed search at 100 M points (four chunks, the bounded tile kernel from the second on) against the
+    resident search of the same cloud, bit for bit; a sample of the rows against the oracle's brute force."""
+    n, m, k, seed = 100_000_000, 400_000, 8, 0x5E
+    src = oracle.synth_xyz(seed, 0, n)
+    tgt = oracle.synth_xyz(seed, 1, m)
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.build(src)
+        wi, wd = p.query(tgt, k)
+        p.set_targets(tgt)
+        gi, gd = p.stream_query(src, n // 4, k)
+    assert np.array_equal(gi, wi.astype(np.uint64)) and np.array_equal(gd, wd)
+    rows = np.arange(0, m, m // 40)
+    sub = np.abs(src[0][None, :] - tgt[0][rows][:, None]).min(axis=0) < 0.02   # (the brute force only needs the points near the sampled rows in x)
+    cand = np.nonzero(sub)[0]
+    ri, rd = oracle.knn_bruteforce(src[:, cand], tgt[:, rows], k)
+    assert np.array_equal(cand[ri].astype(np.uint32), wi[rows]) and np.array_equal(rd, wd[rows])
 
 
 # ---- native slab exchange behind the C ABI (pt_exchange_*): same phases as the RCCL path, device copies as transport ------------
