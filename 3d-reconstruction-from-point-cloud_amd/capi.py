@@ -39,7 +39,7 @@ class Stats(C.Structure):
         ("ms_kernel", C.c_double * 8), ("n_leftover", C.c_uint64), ("rho_occupied", C.c_double),
         ("n_refine", C.c_int32), ("bbox_guess", C.c_int32), ("ms_bake", C.c_double),
         ("n_nodes", C.c_uint32), ("refine_levels", C.c_int32), ("max_cell_points", C.c_uint32), ("n_wave", C.c_uint32),
-        ("pass1_pooled", C.c_int32), ("stream_skipped", C.c_int32), ("stream_revisited", C.c_int32), ("_pad2", C.c_int32),
+        ("pass1_pooled", C.c_int32), ("stream_skipped", C.c_int32), ("stream_revisited", C.c_int32), ("pass2_pooled", C.c_int32),
     ]
 
 

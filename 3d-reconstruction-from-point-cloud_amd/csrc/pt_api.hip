@@ -63,6 +63,8 @@ struct pt_ctx {
   bool bbox_guess_ok = true;   // big clouds: lay the grid out from a sampled bounding box (cleared when a guess failed; reset by an upload)
   bool stream_bounds = true;   // pt_stream_query: later chunks are searched under the targets' current k-th distances and skipped when out of reach ("stream_bounds", a measurement switch)
   bool tile_bounds = false;    // run_query: bounds come with every target of the set (the tile kernel's bounded variant may take them)
+  bool pool2_ok = true, pool2 = true, uniform_seen = false;   // pass 2 without its histogram: allowed ("pool2"), not failed yet on this cloud, and the last build of
+                               // this resident cloud found it uniform (reset by an upload together with pool_ok)
   bool pool_ok = true;         // big clouds, two-level sorts: pass 1 without its histogram pass (cleared when a bin outgrew its sampled region; reset by an upload)
   uint64_t pool_min_points = 32u << 20;   // ... from this size up ("pool_min_points"; 0 switches the pooled pass 1 off)
   int n_cu = 256;              // compute units of the device: persistent workgroups of the pooled pass 1
@@ -168,7 +170,7 @@ int finish(pt_ctx* c) {
 }
 
 // carve the SortTables of one sort out of a single allocation
-int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32_t npoints, size_t rec_size, uint64_t pool_records = 0) {
+int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32_t npoints, size_t rec_size, uint64_t pool_records = 0, uint64_t pool2_records = 0) {
   const size_t small = PT_MAXBINS + 8;
   const size_t words = small * 4 /*counts1,start1,cursor1,tile_first2*/ + 16 /*tile_first1, seg_start1*/ +
                        ((size_t)nblocks + 8) * 3 + ((size_t)nblocks / 2048 + 16);
@@ -177,9 +179,10 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
   const size_t nchunks = pt_sort_num_chunks(npoints, rec_size), nbins1 = ngrp + 1;
   const size_t chunk_words = nblocks > PT_MAXBINS ? (nchunks + 1) * nbins1 + (nchunks / 64 + 2) * nbins1 : 0;
   const size_t bid_points = std::max<uint64_t>(npoints, pool_records);             // (the pooled pass 1 writes ids for its slack and scratch area too)
-  const size_t bid_words = nblocks > PT_MAXBINS && !gsh ? (bid_points + 3) / 2 + 12 : 0;     // u16 per point, two-level sorts only; 16-byte aligned, 16 bytes of slack (read 8 at a time)
+  const size_t bid_words = nblocks > PT_MAXBINS && !gsh && !pool2_records ? (bid_points + 3) / 2 + 12 : 0;     // (a pooled pass 2 reads no block ids)     // u16 per point, two-level sorts only; 16-byte aligned, 16 bytes of slack (read 8 at a time)
   const size_t mac_words = gsh ? (nmacP + 8) * 4 : 0;
-  RES(c, mem, (words + chunk_words + bid_words + mac_words + 16 + 2 * small + 8) * sizeof(uint32_t));
+  const size_t rstart_words = pool2_records ? (size_t)nblocks + 8 : 0;
+  RES(c, mem, (words + chunk_words + bid_words + mac_words + 16 + 2 * small + 8 + rstart_words) * sizeof(uint32_t));
   uint32_t* p = (uint32_t*)mem.p;
   tb.counts1 = p; p += small;
   tb.start1 = p; p += small;
@@ -199,6 +202,8 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
   tb.countsM = tb.startM = tb.cursorM = tb.tile_firstM = nullptr;
   if (gsh) { tb.countsM = p; p += nmacP + 8; tb.startM = p; p += nmacP + 8; tb.cursorM = p; p += nmacP + 8; tb.tile_firstM = p; p += nmacP + 8; }
   tb.pool_est = p; p += small; tb.pool_limit = p; p += small; tb.pool_flag = p; p += 8;
+  tb.rstart = rstart_words ? p : nullptr; p += rstart_words;
+  tb.pool2_records = pool2_records;
   tb.pool_records = pool_records; tb.pool_nwg = (uint32_t)c->n_cu;
   tb.occupied = nullptr;
   tb.shadow32 = nullptr;
@@ -328,8 +333,10 @@ int rebuild(pt_ctx* c) {
   c->st.n_refine = 0;
   uint32_t max_cell = 0;            // points of the fullest cell of the final grid (adaptive builds)
   bool pool_failed = false;         // the pooled pass 1 overflowed a region and the build was redone with the exact pass 1
+  bool pool2_failed = false;        // the same for the pooled pass 2
   for (int iter = 0;; ++iter) {
     choose_grid(c, mn, mx, force_h);
+    int pad_cells[3] = {0, 0, 0};         // empty cells around the cloud on every side (a grid laid out from a sampled box)
     if (guessed && iter == 0) {           // widen the sampled box into the grid's own padding; no room on some axis: no guess
       int pad[3];
       bool room = c->gp.nblocks > PT_MAXBINS;     // (the one-level sort has no chunked pass 1 to verify in)
@@ -338,7 +345,7 @@ int rebuild(pt_ctx* c) {
         room = room && pad[a] >= 1;
       }
       if (room) {
-        for (int a = 0; a < 3; ++a) { c->gp.bbmin[a] -= pad[a] * c->gp.h; c->gp.dim[a] += 2 * pad[a]; }
+        for (int a = 0; a < 3; ++a) { c->gp.bbmin[a] -= pad[a] * c->gp.h; c->gp.dim[a] += 2 * pad[a]; pad_cells[a] = pad[a]; }
       } else {
         guessed = false;
         { int r = source_bbox(c, 1u, mn, mx); if (r != PT_OK) return r; }
@@ -353,9 +360,16 @@ int rebuild(pt_ctx* c) {
     uint64_t pool_records = 0;
     if (c->pool_ok && c->pool_min_points && c->n >= c->pool_min_points && nblocks > PT_MAXBINS && !pt_sort_group_shift(nblocks))
       pool_records = pt_sort_pool_records((uint32_t)c->n, nblocks / PT_MACRO_BLOCKS, (uint32_t)c->n_cu, recsize(c->src_type));
+    // a resident cloud whose last build found it uniform (no refinement of the cell size, occupied cells at rho) takes pass 2 without its
+    // histogram too: block regions from the macro counts (pt_grid.hip, pool2_sizes_kernel); the pass-2 output then carries slack
+    uint64_t pool2_records = 0;
+    if (c->pool2_ok && c->pool2 && c->uniform_seen && nblocks > PT_MAXBINS && !pt_sort_group_shift(nblocks) && c->n)
+      pool2_records = pt_sort_pool2_records(pool_records ? c->n + (uint64_t)(nblocks / PT_MACRO_BLOCKS) * c->n_cu * 128u : c->n, nblocks, recsize(c->src_type));
     RES(c, c->rec, std::max<size_t>(std::max<uint64_t>(c->n, pool_records), 1) * recsize(c->src_type));
-    RES(c, c->rec_tmp, std::max<size_t>(c->n, 1) * recsize(c->src_type));
-    { int r = make_tables(c, c->stb_mem, c->stb, nblocks, (uint32_t)c->n, recsize(c->src_type), pool_records); if (r != PT_OK) return r; }
+    RES(c, c->rec_tmp, std::max<size_t>(std::max<uint64_t>(c->n, pool2_records), 1) * recsize(c->src_type));
+    { int r = make_tables(c, c->stb_mem, c->stb, nblocks, (uint32_t)c->n, recsize(c->src_type), pool_records, pool2_records); if (r != PT_OK) return r; }
+    for (int a = 0; a < 3; ++a) { c->stb.occ_lo[a] = pad_cells[a]; c->stb.occ_hi[a] = c->gp.dim[a] - pad_cells[a]; }
+    c->st.pass2_pooled = pool2_failed ? -1 : (pool2_records ? 1 : 0);
     c->st.pass1_pooled = pool_failed ? -1 : (pool_records ? 1 : 0);
     c->stb.ev = c->sev;
     c->rec32_valid = false;
@@ -369,7 +383,8 @@ int rebuild(pt_ctx* c) {
     if (verify) pt_launch_bbox_init((uint64_t*)c->bbox6.p, c->stream);
     uint64_t* bv = verify ? (uint64_t*)c->bbox6.p : nullptr;
     { const int r = c->in_half ? run_source_sort<__half, RecF>(c, bv) : (c->src_type == PT_F32 ? run_source_sort<float, RecF>(c, bv) : run_source_sort<double, RecD>(c, bv)); if (r != PT_OK) return r; }
-    if (pool_records) {       // did every bin stay inside the region its sample gave it?  (read with the bounding box below when there is one)
+    c->h_counter[15] = 0;
+    if (pool_records || pool2_records) {   // did every bin stay inside the region its estimate gave it?  (read with the bounding box below when there is one)
       HIPCHK(c, hipMemcpyAsync(c->h_counter + 15, c->stb.pool_flag, 4, hipMemcpyDeviceToHost, c->stream));
       if (!verify) HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -388,14 +403,15 @@ int rebuild(pt_ctx* c) {
         c->bbox_guess_ok = false;
         guessed = false;
         force_h = 0.0;
-        if (pool_records && c->h_counter[15]) c->pool_ok = false;
+        if (c->h_counter[15] & 1u) c->pool_ok = false;
+        if (c->h_counter[15] & 2u) c->pool2_ok = false;
         --iter;
         continue;
       }
     }
-    if (pool_records && c->h_counter[15]) {       // a bin outgrew its region (the sample missed a cluster): the same grid again, exactly, and no
-      c->pool_ok = false;                         // more pooling for this cloud
-      pool_failed = true;
+    if (c->h_counter[15]) {                       // a bin outgrew its region (the sample missed a cluster; a macro block is not uniform inside):
+      if (c->h_counter[15] & 1u) { c->pool_ok = false; pool_failed = true; }       // the same grid again with exact bins, and no more pooling of
+      if (c->h_counter[15] & 2u) { c->pool2_ok = false; pool2_failed = true; }     // that pass for this cloud
       guessed = false;                            // (the box is exact by now, or was never guessed)
       --iter;
       continue;
@@ -469,6 +485,9 @@ int rebuild(pt_ctx* c) {
     c->e_src = (float)(amax * 5.9604645e-8 * 1.000001);         // 2^-24 relative rounding, rounded up
     c->rec32_valid = std::isfinite(c->e_src) && amax < 1e30;  // (coordinates an fp32 cannot hold: the group kernel answers)
   }
+  // what the next build of this resident cloud may assume: a cloud whose occupied cells hold about rho points without any refinement of
+  // the cell size is uniform enough for block regions sized from the macro counts (verified again by that build's overflow flag)
+  c->uniform_seen = c->adaptive && c->n && c->st.n_refine == 0 && !c->grid_capped && c->st.rho_occupied > 0.0 && c->st.rho_occupied <= 1.25 * c->rho;
   c->built = true;
   c->st.n_source = c->n;
   c->st.grid_dim[0] = c->gp.dim[0]; c->st.grid_dim[1] = c->gp.dim[1]; c->st.grid_dim[2] = c->gp.dim[2];
@@ -854,6 +873,7 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!strcmp(name, "wave_force")) { c->wave_force = value != 0; return PT_OK; }
   if (!strcmp(name, "wave_min")) { if (!(value >= 0 && value <= 4e9)) return fail(c, PT_ERR_ARG, "wave_min out of range"); c->wave_min = (uint32_t)value; return PT_OK; }
   if (!strcmp(name, "refine_threshold")) { if (!(value >= 0 && value <= 1e9)) return fail(c, PT_ERR_ARG, "refine_threshold out of range"); c->refine_threshold = value; return PT_OK; }
+  if (!strcmp(name, "pool2")) { c->pool2 = value != 0; c->pool2_ok = true; return PT_OK; }    // pass 2 without its histogram on clouds found uniform (1, default) or never (0)
   if (!strcmp(name, "stream_bounds")) { c->stream_bounds = value != 0; return PT_OK; }
   if (!strcmp(name, "pool_min_points")) { c->pool_min_points = value < 0 ? 0 : (uint64_t)value; c->pool_ok = true; return PT_OK; }   // pooled pass 1 from this size up (0: never)
   if (!strcmp(name, "guess_min_points")) { c->guess_min_points = value < 1 ? 1 : (uint64_t)value; return PT_OK; }   // sampled-bbox builds from this size up   // 0 group kernel only, 1 auto, 2 small tiles, 3 large tiles
@@ -891,7 +911,7 @@ int pt_build_aos(pt_ctx* c, const pt_point* cloud, uint64_t n) {
   { int r = copy_in(c, c->aos_stage.p, cloud, n * sizeof(pt_point), 0); if (r) return r; }
   double* x = (double*)c->in_xyz.p;
   pt_launch_aos_split(c->aos_stage.p, (uint32_t)n, x, x + n, x + 2 * n, (Attr*)c->attr.p, c->stream);
-  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
+  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -914,7 +934,7 @@ int pt_build_soa_indexed(pt_ctx* c, const void* xyz, int xyz_type, const uint32_
   }
   c->src_type = xyz_type; c->n = n; c->has_gidx = gidx != nullptr; c->built = false;
   if (!gidx) { c->n_total = n; c->has_attr = false; }
-  c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
+  c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -996,7 +1016,7 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
   else { double* x = (double*)c->in_xyz.p; pt_launch_synth_xyz<double>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream); }
   RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
   pt_launch_synth_attr(seed, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
-  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
+  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -1372,7 +1392,7 @@ int pt_upload_end(pt_ctx* c) {
   if (c->up_attr) pt_launch_pack_attr((const uint8_t*)c->up_rgb.p, (const float*)c->up_nrm.p, (uint32_t)n, (Attr*)c->attr.p, c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));                                // the caller's buffers are free again
   c->src_type = c->up_type; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = c->up_attr != 0; c->built = false;
-  c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
+  c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
   c->up_type = -1;
   release(c, c->up_rgb); release(c, c->up_nrm);
   return rebuild(c);
@@ -1449,7 +1469,7 @@ int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64
       const uint64_t f0 = ch * chunk_points, cnt = std::min<uint64_t>(chunk_points, n - f0);
       c->in_xyz = stage[b];
       c->src_type = xyz_type; c->n = cnt; c->n_total = cnt; c->has_gidx = false; c->has_attr = false; c->built = false;
-      c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
+      c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
     };
     auto bounds_and_reach = [&](uint64_t ch, int backward, uint32_t& reach) -> int {
       const double* mn = &boxes[(size_t)ch * 6];

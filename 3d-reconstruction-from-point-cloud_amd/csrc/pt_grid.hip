@@ -305,7 +305,8 @@ __global__ __launch_bounds__(WG) void hist_kernel(Loader in, GridParams gp, BinS
 template <class Loader, int ITEMS, int SW>
 __global__ __launch_bounds__(SW) void scatter_kernel(Loader in, typename Loader::Rec* __restrict__ out, GridParams gp, BinSpec bs,
                                                      const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ tile_first, int nseg,
-                                                     uint32_t* cursor, const uint32_t* __restrict__ seg_end = nullptr) {
+                                                     uint32_t* cursor, const uint32_t* __restrict__ seg_end = nullptr,
+                                                     const uint32_t* __restrict__ limit = nullptr, uint32_t* flag = nullptr, uint32_t scratch_base = 0) {
   using Rec = typename Loader::Rec;
   constexpr uint32_t TILE = SW * ITEMS;
   constexpr int BPT = PT_MAXBINS / SW;            // bins per thread in the scan
@@ -354,7 +355,15 @@ __global__ __launch_bounds__(SW) void scatter_kernel(Loader in, typename Loader:
     for (int i = 0; i < BPT; ++i) {
       const int b = threadIdx.x * BPT + i;
       binA[b] = ex;
-      if (c[i]) binB[b] = atomicAdd(&cursor[global_bin(bs, seg, b)], c[i]) - ex;   // one reservation per (tile, bin)
+      if (c[i]) {
+        const uint32_t gb = global_bin(bs, seg, b);
+        const uint32_t base = atomicAdd(&cursor[gb], c[i]);                         // one reservation per (tile, bin)
+        // limit != null (pooled pass 2): the bins are REGIONS sized from an estimate (limit[gb + 1] = where bin gb's region ends); a
+        // share that does not fit goes to the scratch area and raises the flag -- the host redoes the build with exact bin sizes
+        const uint32_t lim = limit ? min(limit[gb + 1], scratch_base) : 0xFFFFFFFFu;      // (regions beyond the allocation count as full)
+        if (limit && (base > lim || c[i] > lim - base)) { atomicOr(flag, 2u); binB[b] = scratch_base - ex; }
+        else binB[b] = base - ex;
+      }
       ex += c[i];
     }
   }
@@ -775,6 +784,41 @@ __global__ __launch_bounds__(WG) void pool_finish_kernel(PoolTables pt, int nbin
   if (threadIdx.x == 0) { tile_first[nbins] = tot; pt.flag[2] = totc; }
 }
 
+// ---- pass 2 WITHOUT its histogram (round 3; clouds the previous build of the same resident cloud found uniform) -------------------
+// Pass 2's scatter already takes its space with one atomic per (tile, block); what the histogram + scan before it provided were the
+// blocks' exact STARTS.  Regions sized from an estimate do as well: a block's expected population is its macro segment's count times
+// the share of the macro's cells (inside the grid, outside the empty padding of a sampled bounding box) that are the block's, plus 6 sigma
+// and a constant (a 2048-point block: + 15 %); the scatter counts as it goes,
+// the counts are scanned AFTER it, and finalize reads every block from the start of its region and writes it to its exact place.
+// Gone: the 2-byte block ids pass 1 wrote beside the records (16-byte pieces: 5.7 GB of write traffic for 2 GB of ids) and the pass that
+// read them.  A block that outgrows its region (a cloud that is not uniform inside its macro blocks after all) raises flag bit 2.
+struct OccBox { int lo[3], hi[3]; };
+__global__ __launch_bounds__(WG) void pool2_sizes_kernel(GridParams gp, OccBox ob, const uint32_t* __restrict__ macro_count, uint32_t nblocks, uint32_t* __restrict__ rsize) {
+  const uint32_t b = blockIdx.x * WG + threadIdx.x;
+  if (b > nblocks) return;
+  if (b == nblocks) { rsize[b] = 0; return; }
+  const uint32_t macro = b >> 9, m9 = b & 511u;
+  const int mx = (int)(macro % (uint32_t)gp.mdim[0]), my = (int)((macro / (uint32_t)gp.mdim[0]) % (uint32_t)gp.mdim[1]), mz = (int)(macro / (uint32_t)(gp.mdim[0] * gp.mdim[1]));
+  const int bx = mx * 8 + (int)((m9 & 1u) | ((m9 >> 2) & 2u) | ((m9 >> 4) & 4u));
+  const int by = my * 8 + (int)(((m9 >> 1) & 1u) | ((m9 >> 3) & 2u) | ((m9 >> 5) & 4u));
+  const int bz = mz * 8 + (int)(((m9 >> 2) & 1u) | ((m9 >> 4) & 2u) | ((m9 >> 6) & 4u));
+  // cells of [lo, lo + len) the cloud is expected to occupy: inside the grid, and not in the empty padding a sampled bounding box was given
+  auto inside = [](int lo, int len, int olo, int ohi) { return max(0, min(lo + len, ohi) - max(lo, olo)); };
+  const double cov_b = (double)inside(bx * 8, 8, ob.lo[0], ob.hi[0]) * inside(by * 8, 8, ob.lo[1], ob.hi[1]) * inside(bz * 8, 8, ob.lo[2], ob.hi[2]);
+  const double cov_m = (double)inside(mx * 64, 64, ob.lo[0], ob.hi[0]) * inside(my * 64, 64, ob.lo[1], ob.hi[1]) * inside(mz * 64, 64, ob.lo[2], ob.hi[2]);
+  const double e = cov_m > 0.0 ? (double)macro_count[macro] * cov_b / cov_m : 0.0;
+  rsize[b] = (uint32_t)(e + 6.0 * sqrt(e) + 48.0);          // (48 also for blocks expected empty: outliers the sampled box missed land there)
+}
+__global__ __launch_bounds__(WG) void pool2_check_kernel(const uint32_t* __restrict__ rstart, uint32_t nblocks, uint32_t capacity, uint32_t* flag) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && rstart[nblocks] > capacity) atomicOr(flag, 2u);      // the regions do not fit the allocation
+}
+__global__ __launch_bounds__(WG) void pool2_counts_kernel(const uint32_t* __restrict__ rstart, const uint32_t* __restrict__ cursor, uint32_t nblocks,
+                                                          uint32_t* __restrict__ count) {
+  const uint32_t b = blockIdx.x * WG + threadIdx.x;
+  if (b > nblocks) return;
+  count[b] = b < nblocks ? min(cursor[b], rstart[b + 1]) - rstart[b] : 0u;
+}
+
 // pass-2 histogram from the block ids pass 1 left beside the records: same tiling and flush as hist_kernel
 template <int ITEMS>
 __global__ __launch_bounds__(WG) void hist_bid_kernel(const uint16_t* __restrict__ bid, int nbins, const uint32_t* __restrict__ seg_start,
@@ -835,7 +879,7 @@ __device__ inline void put_shadow(RecF* shadow, uint32_t pos, double x, double y
 template <class Rec>
 __global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ in, Rec* __restrict__ out, GridParams gp,
                                                        const uint32_t* __restrict__ block_start, uint32_t* cell_start, uint32_t* occupied,
-                                                       RecF* __restrict__ shadow) {
+                                                       RecF* __restrict__ shadow, const uint32_t* __restrict__ in_start = nullptr) {
   constexpr int FSTAGE = 64 * 1024 / (int)sizeof(Rec);        // records of a block that fit the 64-KB output stage
   static_assert(FSTAGE <= FWG * FITEMS, "staged blocks are register-resident blocks");
   __shared__ uint32_t cnt[PT_BLOCK_CELLS];
@@ -843,6 +887,8 @@ __global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ i
   __shared__ Rec stage[FSTAGE];
   const uint32_t b = blockIdx.x;
   const uint32_t s = block_start[b], e = block_start[b + 1];
+  // (pooled pass 2: the block's records sit at the start of its REGION in `in`, not at its final place)
+  if (in_start) in += (ptrdiff_t)in_start[b] - (ptrdiff_t)s;
   if (s == e) {   // empty block: only the table
     if (occupied && threadIdx.x == 0) occupied[b] = 0;
     if (cell_start) {
@@ -974,6 +1020,14 @@ uint64_t pt_sort_pool_records(uint32_t n, uint32_t nbins, uint32_t nwg, size_t r
   const uint64_t tile1 = (uint64_t)1024 * (rec_size == 16 ? 8 : 4);
   const uint64_t total = (uint64_t)(regions * 1.02) + 4096 + tile1;
   return total < 0xFFFFFF00ull ? total : 0;                    // (positions are 32-bit)
+}
+// The pooled pass 2's capacity (records of the pass-2 output): regions e_b + 6 sqrt(e_b) + 48 over all blocks, with sum(e_b) = n_in (what
+// pass 1 left, sentinels included) and sum(sqrt(e_b)) <= sqrt(nblocks n_in); plus 1 % and the scratch area of one tile.  0 = too large.
+uint64_t pt_sort_pool2_records(uint64_t n_in, uint32_t nblocks, size_t rec_size) {
+  if (!n_in || !nblocks) return 0;
+  const double regions = (double)n_in + 6.0 * std::sqrt((double)nblocks * (double)n_in) + 49.0 * (double)nblocks;
+  const uint64_t total = (uint64_t)(regions * 1.01) + 4096 + (uint64_t)pt_sort_tile_points(rec_size);
+  return total < 0xFFFFFF00ull ? total : 0;
 }
 uint32_t pt_sort_num_chunks(uint32_t n, size_t rec_size) {
   const uint32_t tile = (uint32_t)pt_sort_tile_points(rec_size);
@@ -1107,6 +1161,26 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
   }
   // two levels: planar -> out_final (by macro block) -> tmp (by block) -> out_final (by cell)
   const BinSpec b1{0, 9, (int)nmacro};
+  // pass 2 + finalize without the pass-2 histogram (pool2_sizes_kernel): regions from the macro counts, counts scanned after the scatter
+  auto pooled_pass2 = [&](uint32_t ntiles2, const uint32_t* seg_end) {
+    RecLoader<Rec> rl{out_final};
+    const uint32_t scratch2 = (uint32_t)(tb.pool2_records - TILE);
+    OccBox ob;
+    for (int a = 0; a < 3; ++a) { ob.lo[a] = tb.occ_lo[a]; ob.hi[a] = tb.occ_hi[a]; }
+    hipLaunchKernelGGL(pool2_sizes_kernel, dim3((nblocks + 1 + WG - 1) / WG), dim3(WG), 0, s, gp, ob, tb.counts1, nblocks, tb.block_count);
+    pt_launch_scan_u32(tb.block_count, tb.rstart, nblocks + 1, tb.scan_tmp, s);
+    hipLaunchKernelGGL(pool2_check_kernel, dim3(1), dim3(WG), 0, s, tb.rstart, nblocks, scratch2, tb.pool_flag);
+    ck(hipMemcpyAsync(tb.cursor2, tb.rstart, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s));
+    mark(3);
+    hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS_S, SW>), dim3(ntiles2), dim3(SW), 0, s, rl, tmp, gp, b2, tb.start1, tb.tile_first2,
+                       (int)nmacro, tb.cursor2, seg_end, tb.rstart, tb.pool_flag, scratch2);
+    mark(4);
+    hipLaunchKernelGGL(pool2_counts_kernel, dim3((nblocks + 1 + WG - 1) / WG), dim3(WG), 0, s, tb.rstart, tb.cursor2, nblocks, tb.block_count);
+    pt_launch_scan_u32(tb.block_count, tb.block_start, nblocks + 1, tb.scan_tmp, s);
+    if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start, tb.occupied, tb.shadow32, tb.rstart);
+    mark(5);
+  };
+  const bool pool2 = tb.pool2_records && n && do_finalize;
   if (tb.pool_records && n) {
     // pass 1 without its histogram pass: regions from a sample, blocks, sentinels (scatter_pool_kernel); pass 2 reads every bin from its
     // region's start to where pass 1 stopped (seg_end) and drops the sentinels
@@ -1123,11 +1197,12 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
     mark(1);
     const uint32_t nt1 = (uint32_t)(((uint64_t)n + TILE1 - 1) / TILE1);
     hipLaunchKernelGGL((scatter_pool_kernel<PlanarLoader<T>, ITEMS_S, 1024>), dim3(std::min(tb.pool_nwg, nt1)), dim3(1024), 0, s, pl, out_final, gp, b1, n, pt,
-                       scratch, tb.bid, bbox6_verify);
+                       scratch, pool2 ? (uint16_t*)nullptr : tb.bid, bbox6_verify);
     hipLaunchKernelGGL(pool_finish_kernel, dim3(1), dim3(WG), 0, s, pt, (int)nmacro, TILE, tb.counts1, tb.tile_first2);
     mark(2);
     RecLoader<Rec> rl{out_final};
     const uint32_t ntiles2 = (uint32_t)(((uint64_t)n + (uint64_t)nmacro * tb.pool_nwg * POOL_B) / TILE) + nmacro + 1;
+    if (pool2) { pooled_pass2(ntiles2, tb.cursor1); return done(out_final); }
     const int tpw = 4;
     hipLaunchKernelGGL((hist_bid_kernel<ITEMS>), dim3((ntiles2 + tpw - 1) / tpw), dim3(WG), 0, s, tb.bid, (int)PT_MACRO_BLOCKS, tb.start1,
                        tb.tile_first2, (int)nmacro, tb.block_count, tpw, tb.cursor1);
@@ -1157,14 +1232,19 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
     hipLaunchKernelGGL(colapply_kernel, dim3(ngroups, (nmacro + COL_WG - 1) / COL_WG), dim3(COL_WG), 0, s, tb.chunk_hist, (int)nchunks, (int)nmacro, tb.chunk_gsum, tb.start1);
     if (chunk_tiles % 2 == 0)     // big clouds: 1024-thread workgroups, tiles twice as long -> twice the bytes per bin and tile
       hipLaunchKernelGGL((scatter_chunk_kernel<PlanarLoader<T>, ITEMS_S, 2 * SW>), dim3(nchunks), dim3(2 * SW), 0, s, pl, out_final, gp, b1, n,
-                         chunk_tiles / 2, tb.chunk_hist, tb.bid);
+                         chunk_tiles / 2, tb.chunk_hist, pool2 ? (uint16_t*)nullptr : tb.bid);
     else
       hipLaunchKernelGGL((scatter_chunk_kernel<PlanarLoader<T>, ITEMS_S, SW>), dim3(nchunks), dim3(SW), 0, s, pl, out_final, gp, b1, n, chunk_tiles,
-                         tb.chunk_hist, tb.bid);
+                         tb.chunk_hist, pool2 ? (uint16_t*)nullptr : tb.bid);
   }
   mark(2);
   RecLoader<Rec> rl{out_final};
   const uint32_t ntiles2 = ntiles + nmacro;   // upper bound: every segment adds at most one partial tile
+  if (pool2) {
+    ck(hipMemsetAsync(tb.pool_flag, 0, sizeof(uint32_t) * 4, s));
+    pooled_pass2(ntiles2, nullptr);
+    return done(out_final);
+  }
   if (n) {
     const int tpw = 4;
     hipLaunchKernelGGL((hist_bid_kernel<ITEMS>), dim3((ntiles2 + tpw - 1) / tpw), dim3(WG), 0, s, tb.bid, (int)PT_MACRO_BLOCKS, tb.start1,

@@ -30,6 +30,10 @@ struct SortTables {
   uint32_t* pool_est;    // [PT_MAXBINS]  sample counts
   uint32_t* pool_limit;  // [PT_MAXBINS]  end of every bin's region
   uint32_t* pool_flag;   // [4] {a region overflowed, points sampled, records incl. sentinels after pass 1, -}
+  int occ_lo[3], occ_hi[3];  // pooled pass 2: the cells [occ_lo, occ_hi) per axis the cloud is expected to occupy (a grid laid out from a sampled
+                         // bounding box carries empty padding cells around it; the whole grid otherwise)
+  uint32_t* rstart;      // [nblocks+1] pooled pass 2: where every block's region starts in the pass-2 output
+  uint64_t pool2_records;// capacity (records) of the pass-2 output when pass 2 is pooled (0: exact pass 2), scratch area included
   uint64_t pool_records; // capacity (records) of the pass-1 output and of `bid`, scratch area of one tile at its end included
   uint32_t pool_nwg;     // persistent workgroups of the pooled pass 1 (one per CU)
   hipError_t* status;    // optional: receives the first HIP error of the sort's launch path (hipSuccess otherwise)
@@ -56,6 +60,7 @@ int pt_sort_tile_points(size_t rec_size);
 // capacity (records) the pooled pass 1 needs for n points in nbins bins with nwg persistent workgroups: the regions' worst case
 // for ANY distribution of the sample over the bins, plus the scratch area; 0 = the cloud is not pooled (too small, too large)
 uint64_t pt_sort_pool_records(uint32_t n, uint32_t nbins, uint32_t nwg, size_t rec_size);
+uint64_t pt_sort_pool2_records(uint64_t n_in, uint32_t nblocks, size_t rec_size);
 // grids of more than PT_MAXBINS macro blocks: pass 1 partitions by GROUPS of 2^shift macro blocks (at most PT_MAXBINS groups)
 inline int pt_sort_group_shift(uint32_t nblocks) {
   const uint32_t nm = nblocks / PT_MACRO_BLOCKS;

@@ -96,7 +96,8 @@ typedef struct pt_stats_t {
                              * -1 a bin outgrew its sampled region and the build was redone with the exact pass 1; 0 exact pass 1 */
   int32_t stream_skipped;   /* last pt_stream_query: (chunk, forward sweep) steps it did not search because no target's bound reached the chunk's box */
   int32_t stream_revisited; /* ... and chunks its backward sweep brought back for targets that lay outside them before they had a list */
-  int32_t _pad2;
+  int32_t pass2_pooled;     /* last build: 1 pass 2 took its block regions from the macro counts (no pass-2 histogram: a rebuild of a resident cloud the
+                             * previous build found uniform); -1 a block outgrew its region and the build was redone exactly; 0 exact pass 2 */
 } pt_stats_t;
 
 /* ---- context ------------------------------------------------------------------------ */
@@ -116,7 +117,9 @@ int  pt_set_stream(pt_ctx*, void* hip_stream);
  * sample and verify it during the first partition pass instead of spending a pass on the exact box; default 8 Mi),
  * "pool_min_points" (clouds at least this large, on the two-level sort, size the bins of the first partition pass from a sample
  * instead of a histogram pass over the whole cloud -- with slack, and a flag that sends the build back to the exact histogram when a
- * bin outgrows its estimate; default 32 Mi, 0 = never),
+ * bin outgrows its estimate; default 32 Mi, 0 = never), "pool2" (1, default: a rebuild of a resident cloud that the previous build
+ * found uniform -- no refinement, occupied cells at rho -- also sizes the blocks of the second partition pass from the macro counts
+ * instead of a histogram pass, verified the same way; 0 = never),
  * "refine_threshold" (grid cells holding more points than this get an 8x8x8 sub-grid, recursively up to three levels, which
  * searches descend into instead of scanning the cell end to end -- clouds with strong density contrast; default 8192, 0 = never),
  * "wave_min" (on such clouds a target whose 27 nearest cells hold at least this many points is answered by a whole wave instead of

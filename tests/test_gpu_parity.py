@@ -674,6 +674,58 @@ def test_pooled_pass1_on_small_clouds(pkg, oracle, f64, slab):
     assert np.array_equal(idx2, wi) and np.array_equal(d22, wd)
 
 
+@pytest.mark.parametrize("f64,pool1", [(False, False), (True, False), (False, True)])
+def test_pooled_pass2_on_a_uniform_cloud(pkg, oracle, f64, pool1):
+    """A rebuild of a resident cloud that the previous build found uniform sizes the blocks of pass 2 from the macro counts (no pass-2
+    histogram, no block ids beside the records): exact like the first build, with the exact and with the pooled pass 1 before it."""
+    rng = np.random.default_rng(91)
+    n, m, k = 3_000_000, 4000, 8
+    src = rng.random((3, n)) if f64 else rng.random((3, n), dtype=np.float32)
+    tgt = rng.random((3, m)).astype(src.dtype)
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        if pool1:
+            p.set_param("pool_min_points", 1)
+        p.build(src)
+        st = p.stats()
+        assert st["n_levels"] == 2 and st["pass2_pooled"] == 0 and st["pass1_pooled"] == (1 if pool1 else 0), st
+        i0, d0 = p.query(tgt, k)
+        p.rebuild()
+        st = p.stats()
+        assert st["pass2_pooled"] == 1 and st["pass1_pooled"] == (1 if pool1 else 0), st
+        i1, d1 = p.query(tgt, k)
+        p.set_param("pool2", 0)
+        p.rebuild()
+        assert p.stats()["pass2_pooled"] == 0
+        i2, d2 = p.query(tgt, k)
+    wi, wd = oracle.KdTree(src.astype(np.float64)).query(tgt.astype(np.float64), k)
+    for gi, gd in ((i0, d0), (i1, d1), (i2, d2)):
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+
+
+def test_pooled_pass2_overflow_falls_back(pkg, oracle):
+    """A cloud whose cells are all occupied at about rho points -- so the build calls it uniform -- but whose density changes several-fold
+    across every macro block: the blocks' regions, sized as if the macro were uniform inside, overflow; the flag sends the rebuild back to
+    the exact pass 2 and the context stops pooling pass 2 for this cloud."""
+    rng = np.random.default_rng(92)
+    n, m, k = 3_000_000, 3000, 8
+    src = rng.random((3, n), dtype=np.float32)
+    src[0] = (0.15 + 0.85 * src[0]) ** 2.0                                   # density ~ 1 / sqrt(x): 2.6 x from one end to the other, no empty region
+    tgt = rng.random((3, m), dtype=np.float32); tgt[0] = (0.15 + 0.85 * tgt[0]) ** 2.0
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.set_param("adaptive", 1)
+        p.build(src)
+        st = p.stats()
+        if not (st["n_refine"] == 0 and st["rho_occupied"] <= 1.25 * 4.0):
+            pytest.skip("the build refined this cloud (rho_occupied %.2f): it never pools pass 2" % st["rho_occupied"])
+        p.rebuild()
+        assert p.stats()["pass2_pooled"] == -1, p.stats()
+        idx, d2 = p.query(tgt, k)
+        p.rebuild()
+        assert p.stats()["pass2_pooled"] == 0
+    wi, wd = oracle.KdTree(src).query(tgt, k)
+    assert np.array_equal(idx, wi) and np.array_equal(d2, wd)
+
+
 def test_pooled_pass1_overflow_falls_back_to_the_exact_histogram(pkg, oracle):
     """A cloud built to fool the sample: the runs the sample reads (one run of 256 points in 64) are uniform, every other point sits in
     one small clump.  The clump's bin outgrows the region its sample gave it, the flag is raised, and the build is redone with the
