@@ -102,3 +102,39 @@ def test_random_fused_blend_matches_oracle(pkg, oracle, case):
     assert np.array_equal(idx.cpu().numpy().view(np.uint32), wi) and np.array_equal(d2.cpu().numpy(), wd), what
     rc, rn = oracle.blend(wi, wd, oracle.synth_rgb(seed, n), oracle.synth_nrm(seed, n), mode)
     assert np.abs(rgb.cpu().numpy() - rc).max() / 255 <= 1e-5 and np.abs(nrm.cpu().numpy() - rn).max() <= 1e-5, what
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("PT_STRESS_POOL_CASES", "8"))))
+def test_random_two_level_pooled_builds_match_oracle(pkg, oracle, case):
+    """The two-level sort with BOTH histogram passes replaced by estimates (round 3: bin regions from a sample for pass 1, block regions
+    from the macro counts for pass 2 on rebuilds) on clouds small enough for the oracle: whatever the cloud -- uniform, lattice, blobs,
+    a sheet -- every build either keeps inside its regions or notices (pt_stats.pass1_pooled / pass2_pooled = -1) and redoes the pass
+    exactly; the answer is the oracle's after the first build and after two rebuilds."""
+    rng = np.random.default_rng(9000 + case)
+    kind = ["uniform", "blobs", "lattice", "sheet"][case % 4]
+    n = int(rng.choice([700_000, 1_500_000])); m = int(rng.choice([500, 6000])); k = int(rng.choice([1, 8, 16, 20]))
+    rho = float(rng.choice([0.5, 1.0]))                                  # fine cells: more than 1024 blocks, i.e. the two-level sort
+    f64 = rng.random() < 0.3
+    src = _cloud(rng, kind, n); tgt = _cloud(rng, kind, m)
+    near = rng.random(m) < 0.3                                           # some targets right on top of source points
+    tgt[:, near] = src[:, rng.integers(0, n, size=int(near.sum()))]
+    if f64:
+        src = src.astype(np.float64) + (rng.random(src.shape) - 0.5) * 1e-9 * (kind != "lattice"); tgt = tgt.astype(np.float64)
+    seen = []
+    with pkg.PointsTransfer(device=0, rho=rho) as p:
+        p.set_param("pool_min_points", 1)
+        if kind == "uniform":
+            p.set_param("refine_cells_per_point", 16.0)
+        p.build(src, xyz_type=pkg.F64 if f64 else None)
+        st = p.stats(); seen.append((st["n_levels"], st["pass1_pooled"], st["pass2_pooled"]))
+        res = [p.query(tgt, k, xyz_type=pkg.F64 if f64 else None)]
+        for _ in range(2):
+            p.rebuild()
+            st = p.stats(); seen.append((st["n_levels"], st["pass1_pooled"], st["pass2_pooled"]))
+            res.append(p.query(tgt, k, xyz_type=pkg.F64 if f64 else None))
+    wi, wd = oracle.KdTree(src).query(tgt, k)
+    what = "case %d: %s n=%d m=%d k=%d rho=%g f64=%d (levels, pass 1, pass 2 per build: %s)" % (case, kind, n, m, k, rho, f64, seen)
+    for gi, gd in res:
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd), what
+    if kind == "uniform":
+        assert seen[0][0] == 2 and seen[0][1] == 1 and seen[1][2] == 1, what        # the pooled passes did run where they are meant to
