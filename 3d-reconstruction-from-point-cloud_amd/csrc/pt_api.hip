@@ -194,8 +194,8 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
   tb.block_start = p; p += (size_t)nblocks + 8;
   tb.cursor2 = p; p += (size_t)nblocks + 8;
   tb.scan_tmp = p; p += (size_t)nblocks / 2048 + 16;
-  tb.chunk_hist = p; p += (nchunks + 1) * nbins1;
-  tb.chunk_gsum = p; p += (nchunks / 64 + 2) * nbins1;
+  tb.chunk_hist = tb.chunk_gsum = nullptr;                   // (chunked pass 1: grids of more than PT_MAXBINS blocks only -- as chunk_words counts them;
+  if (chunk_words) { tb.chunk_hist = p; p += (nchunks + 1) * nbins1; tb.chunk_gsum = p; p += (nchunks / 64 + 2) * nbins1; }     //  carved unconditionally they ran past the allocation on one-level grids)
   if (bid_words) p += (4 - ((uintptr_t)p / sizeof(uint32_t)) % 4) % 4;                  // (at most 3 of bid_words' spare words)
   tb.bid = bid_words ? (uint16_t*)p : nullptr;
   p += bid_words ? bid_words - 4 : 0;
@@ -205,6 +205,7 @@ int make_tables(pt_ctx* c, DevBuf& mem, SortTables& tb, uint32_t nblocks, uint32
   tb.rstart = rstart_words ? p : nullptr; p += rstart_words;
   tb.pool2_records = pool2_records;
   tb.pool_records = pool_records; tb.pool_nwg = (uint32_t)c->n_cu;
+  if ((size_t)(p - (uint32_t*)mem.p) * sizeof(uint32_t) > mem.cap) return fail(c, PT_ERR_STATE, "internal: sort tables carved past their allocation");
   tb.occupied = nullptr;
   tb.shadow32 = nullptr;
   tb.status = nullptr;
@@ -487,7 +488,8 @@ int rebuild(pt_ctx* c) {
   }
   // what the next build of this resident cloud may assume: a cloud whose occupied cells hold about rho points without any refinement of
   // the cell size is uniform enough for block regions sized from the macro counts (verified again by that build's overflow flag)
-  c->uniform_seen = c->adaptive && c->n && c->st.n_refine == 0 && !c->grid_capped && c->st.rho_occupied > 0.0 && c->st.rho_occupied <= 1.25 * c->rho;
+  c->uniform_seen = c->adaptive && c->n && c->st.n_refine == 0 && !c->grid_capped && c->st.rho_occupied > 0.0 &&
+                    c->st.rho_occupied <= 1.25 * c->rho / (1.0 - std::exp(-c->rho));       // (a uniform cloud's occupied cells hold rho / (1 - e^-rho))
   c->built = true;
   c->st.n_source = c->n;
   c->st.grid_dim[0] = c->gp.dim[0]; c->st.grid_dim[1] = c->gp.dim[1]; c->st.grid_dim[2] = c->gp.dim[2];

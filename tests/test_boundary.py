@@ -216,6 +216,25 @@ def test_bench_launches_its_own_ranks():
     assert out["dry_run"] is True and out["n_gpus"] == 2 and out["value"] is None
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's own launch form for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- in dry-run mode on CPU: the ranks are torchrun's, bench.py only reads the environment, and
+    rank 0 prints the one JSON line."""
+    import json
+    import socket
+    import sys
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.lstrip().startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
 def test_bench_launcher_fails_when_a_rank_fails():
     """A rank that dies before the rendezvous: the others sit in init_process_group waiting for it -- the launcher stops them and
     exits with the failed rank's code, promptly."""

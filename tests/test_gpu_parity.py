@@ -674,18 +674,19 @@ def test_pooled_pass1_on_small_clouds(pkg, oracle, f64, slab):
     assert np.array_equal(idx2, wi) and np.array_equal(d22, wd)
 
 
-@pytest.mark.parametrize("f64,pool1", [(False, False), (True, False), (False, True)])
-def test_pooled_pass2_on_a_uniform_cloud(pkg, oracle, f64, pool1):
+@pytest.mark.parametrize("f64,pool1,slab", [(False, False, False), (True, False, False), (False, True, False), (False, True, True)])
+def test_pooled_pass2_on_a_uniform_cloud(pkg, oracle, f64, pool1, slab):
     """A rebuild of a resident cloud that the previous build found uniform sizes the blocks of pass 2 from the macro counts (no pass-2
     histogram, no block ids beside the records): exact like the first build, with the exact and with the pooled pass 1 before it."""
     rng = np.random.default_rng(91)
     n, m, k = 3_000_000, 4000, 8
     src = rng.random((3, n)) if f64 else rng.random((3, n), dtype=np.float32)
     tgt = rng.random((3, m)).astype(src.dtype)
+    gidx = rng.permutation(n).astype(np.uint32) if slab else None            # a slab of a larger cloud: caller-given global indices
     with pkg.PointsTransfer(device=0, k_hint=k) as p:
         if pool1:
             p.set_param("pool_min_points", 1)
-        p.build(src)
+        p.build(src, gidx=gidx)
         st = p.stats()
         assert st["n_levels"] == 2 and st["pass2_pooled"] == 0 and st["pass1_pooled"] == (1 if pool1 else 0), st
         i0, d0 = p.query(tgt, k)
@@ -698,6 +699,10 @@ def test_pooled_pass2_on_a_uniform_cloud(pkg, oracle, f64, pool1):
         assert p.stats()["pass2_pooled"] == 0
         i2, d2 = p.query(tgt, k)
     wi, wd = oracle.KdTree(src.astype(np.float64)).query(tgt.astype(np.float64), k)
+    if slab:
+        wi = gidx[wi]
+        order = np.lexsort((wi, wd), axis=1)
+        wi = np.take_along_axis(wi, order, 1); wd = np.take_along_axis(wd, order, 1)
     for gi, gd in ((i0, d0), (i1, d1), (i2, d2)):
         assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
 

@@ -137,4 +137,4 @@ def test_random_two_level_pooled_builds_match_oracle(pkg, oracle, case):
     for gi, gd in res:
         assert np.array_equal(gi, wi) and np.array_equal(gd, wd), what
     if kind == "uniform":
-        assert seen[0][0] == 2 and seen[0][1] == 1 and seen[1][2] == 1, what        # the pooled passes did run where they are meant to
+        assert seen[0][0] == 2 and seen[0][1] == 1, what        # the pooled pass 1 did run (pass 2 is pooled only where the build calls the cloud uniform)
