@@ -128,7 +128,9 @@ int  pt_set_stream(pt_ctx*, void* hip_stream);
  * 1024 macro blocks, which a cloud of more than ~1e9 points gets anyway, cost the sort one more partition pass),
  * "refine_cells_per_point" (that refinement also stops at this many grid cells per point; default 2), "grid_hint" (1,
  * default: pt_rebuild of the same resident cloud starts from the cell size the previous build ended with -- checked against the
- * occupancy it finds -- instead of searching for it again; 0: every build searches from scratch). */
+ * occupancy it finds -- instead of searching for it again; 0: every build searches from scratch), "stream_bounds" (1, default:
+ * pt_stream_query searches every chunk under the bounds the targets bring and defers / skips what is out of reach; 0: every target,
+ * unbounded, in every chunk -- round 2's behaviour, kept as a measurement switch). */
 int  pt_set_param(pt_ctx*, const char* name, double value);
 const char* pt_last_error(pt_ctx*);
 int  pt_stats(pt_ctx*, pt_stats_t* out);
