@@ -282,6 +282,8 @@ inline bool read_mesh_fast(const std::string& path, FastMesh& mesh, int threads 
 //     (x y z nx ny nz r g b  /  x y z nx ny nz u v r g b), whatever they are called, each converted from its declared type
 //     exactly as the text reader converts a token (through double; colours truncated to int); further properties are
 //     skipped.  Faces: a list property `count, indices...`; the first three indices are kept (the reference assumes triangles).
+//   * clouds whose vertex element declares all nine fields under their usual names are read BY NAME (any order, other properties
+//     skipped: cloud_layout below) by the planar readers; everything else -- and every mesh -- stays positional like the reference.
 //   * clouds can be parsed straight into planar arrays x[] y[] z[] (double), rgb[][3] (bytes, clamped to 0..255 like the
 //     device-side record split does) and nrm[][3] (float) -- 39 bytes per point instead of 80 -- in memory the caller
 //     allocates (pinned, for the CLI), with a callback per finished range of records so that the upload of a range
@@ -291,6 +293,8 @@ struct Header {
   bool binary = false, big_endian = false;
   std::vector<int> vsize;          // byte size of every scalar property of the vertex element, in order
   std::vector<char> vkind;         // 'i' signed, 'u' unsigned, 'f' float, per property
+  std::vector<std::string> vname;  // the properties' names, in order
+  bool vertex_has_list = false;    // a list property inside the vertex element (positional reading only)
   int face_count_size = 1, face_index_size = 4;
   char face_index_kind = 'i';
   const char* body = nullptr;
@@ -341,7 +345,8 @@ inline Header parse_header_full(const char* begin, const char* end) {
     else if (tok.size() >= 2 && tok[0] == "element") element = tok[1];
     else if (tok.size() >= 3 && tok[0] == "property") {
       int sz; char kd;
-      if (element == "vertex" && tok[1] != "list" && detail::type_of(tok[1], sz, kd)) { h.vsize.push_back(sz); h.vkind.push_back(kd); }
+      if (element == "vertex" && tok[1] != "list" && detail::type_of(tok[1], sz, kd)) { h.vsize.push_back(sz); h.vkind.push_back(kd); h.vname.push_back(tok[2]); }
+      else if (element == "vertex" && tok[1] == "list") h.vertex_has_list = true;
       else if (element == "face" && tok[1] == "list" && tok.size() >= 5) {
         int cs, is; char ck, ik;
         if (detail::type_of(tok[2], cs, ck) && detail::type_of(tok[3], is, ik)) { h.face_count_size = cs; h.face_index_size = is; h.face_index_kind = ik; }
@@ -374,6 +379,37 @@ inline void set_cloud_soa(const CloudSoA& o, uint64_t rec, unsigned field, doubl
 }
 }  // namespace detail
 
+// Which declared property feeds which of the nine cloud fields (x y z nx ny nz r g b).  The reference reads POSITIONALLY -- nine
+// tokens per record, whatever the header says (src/pointsTransfer.cpp:204-250) -- and that stays the rule.  One extension, for files
+// the reference would misread anyway: when the vertex element declares ALL nine fields under their usual names (x y z nx ny nz and
+// red green blue, also r g b / diffuse_red ...), in any order and with any other scalar properties beside them (alpha, quality,
+// scalar fields of scanner exports), the fields are taken BY NAME and the rest is skipped.  P = scalar properties (= tokens) per record.
+struct CloudLayout {
+  bool named = false;
+  int P = 9;
+  std::vector<int> fmap;        // per declared property: the field it feeds (0..8) or -1
+};
+inline CloudLayout cloud_layout(const Header& h) {
+  CloudLayout L;
+  static const char* const names[9][3] = {{"x", "", ""}, {"y", "", ""}, {"z", "", ""}, {"nx", "normal_x", ""}, {"ny", "normal_y", ""}, {"nz", "normal_z", ""},
+                                          {"red", "r", "diffuse_red"}, {"green", "g", "diffuse_green"}, {"blue", "b", "diffuse_blue"}};
+  if (h.vertex_has_list || h.vname.size() < 9) return L;
+  std::vector<int> fmap(h.vname.size(), -1);
+  int found = 0;
+  for (int f = 0; f < 9; ++f) {
+    int at = -1;
+    for (size_t p = 0; p < h.vname.size() && at < 0; ++p)
+      for (int a = 0; a < 3; ++a) if (names[f][a][0] && h.vname[p] == names[f][a] && fmap[p] < 0) { at = (int)p; break; }
+    if (at >= 0) { fmap[(size_t)at] = f; ++found; }
+  }
+  if (found != 9) return L;
+  bool positional_already = h.vname.size() == 9;
+  for (int f = 0; f < 9 && positional_already; ++f) positional_already = fmap[(size_t)f] == f;
+  if (positional_already) return L;                     // (the usual file: nothing to do differently)
+  L.named = true; L.P = (int)h.vname.size(); L.fmap = fmap;
+  return L;
+}
+
 // Records of the cloud file at `path` (ASCII or binary little-endian) into planar arrays.  `alloc(bytes)` provides the memory
 // (five calls, once the record count is known; return nullptr to fail), `on_count(n)` announces that count before the first
 // record is parsed (return false to abort), `range_done(first, count)` -- may do nothing -- is
@@ -386,6 +422,7 @@ inline bool read_cloud_soa(const std::string& path, CloudSoA& out, long& declare
   detail::Mapping map;
   if (!map.open(path)) return false;
   const Header h = parse_header_full(map.begin(), map.end());
+  const CloudLayout L = cloud_layout(h);
   declared = h.vertex_count;
   out = CloudSoA();
   if (declared <= 0 || h.body >= map.end()) return true;
@@ -410,10 +447,17 @@ inline bool read_cloud_soa(const std::string& path, CloudSoA& out, long& declare
       const unsigned char* rec = reinterpret_cast<const unsigned char*>(h.body) + r0 * stride;
       for (uint64_t r = r0; r < r1; ++r, rec += stride) {
         const unsigned char* q = rec;
-        for (int f = 0; f < 9; ++f) {
-          double v = 0.0;
-          if (f < nprop) { v = detail::load_scalar(q, h.vsize[(size_t)f], h.vkind[(size_t)f]); q += h.vsize[(size_t)f]; }
-          detail::set_cloud_soa(out, r, (unsigned)f, v);
+        if (L.named) {                                               // fields by name: every declared property is walked, the nine are kept
+          for (int p = 0; p < L.P; ++p) {
+            if (L.fmap[(size_t)p] >= 0) detail::set_cloud_soa(out, r, (unsigned)L.fmap[(size_t)p], detail::load_scalar(q, h.vsize[(size_t)p], h.vkind[(size_t)p]));
+            q += h.vsize[(size_t)p];
+          }
+        } else {
+          for (int f = 0; f < 9; ++f) {
+            double v = 0.0;
+            if (f < nprop) { v = detail::load_scalar(q, h.vsize[(size_t)f], h.vkind[(size_t)f]); q += h.vsize[(size_t)f]; }
+            detail::set_cloud_soa(out, r, (unsigned)f, v);
+          }
         }
       }
       if (r1 > r0) range_done(r0, r1 - r0);
@@ -423,25 +467,29 @@ inline bool read_cloud_soa(const std::string& path, CloudSoA& out, long& declare
   const int parts = detail::resolve_threads(threads, (size_t)(map.end() - h.body));
   const auto cuts = detail::token_cuts(h.body, map.end(), parts);
   const auto first = detail::token_offsets(cuts);
-  const uint64_t n = std::min<uint64_t>((uint64_t)declared, first[(size_t)parts] / 9);
+  const uint64_t P = (uint64_t)L.P;                                  // tokens per record: 9 (the reference's rule), or the declared properties when read by name
+  const uint64_t n = std::min<uint64_t>((uint64_t)declared, first[(size_t)parts] / P);
   if (!n) return true;
   if (!allocate(n)) return false;
-  const uint64_t limit = n * 9;
+  const uint64_t limit = n * P;
   detail::run_parallel(parts, [&](int i) {
     uint64_t g = first[(size_t)i];
     if (g >= limit) return;
     detail::for_each_token(cuts[(size_t)i], cuts[(size_t)i + 1], [&](const char* t, const char* e) {
-      if (g < limit) detail::set_cloud_soa(out, g / 9, (unsigned)(g % 9), detail::token_value(t, e));
+      if (g < limit) {
+        const int fld = L.named ? L.fmap[(size_t)(g % P)] : (int)(g % P);
+        if (fld >= 0) detail::set_cloud_soa(out, g / P, (unsigned)fld, detail::token_value(t, e));
+      }
       ++g;
     });
     // the records this range holds from first to last token
-    const uint64_t r0 = (first[(size_t)i] + 8) / 9, r1 = std::min<uint64_t>(first[(size_t)i + 1], limit) / 9;
+    const uint64_t r0 = (first[(size_t)i] + P - 1) / P, r1 = std::min<uint64_t>(first[(size_t)i + 1], limit) / P;
     if (r1 > r0) range_done(r0, r1 - r0);
   });
   uint64_t last = ~0ull;
   for (int i = 1; i < parts; ++i) {                                  // records cut by a range boundary: complete only now
     const uint64_t g = first[(size_t)i];                             // (several boundaries may cut the same record: reported once)
-    if (g % 9 && g / 9 < n && g / 9 != last) { last = g / 9; range_done(last, 1); }
+    if (g % P && g / P < n && g / P != last) { last = g / P; range_done(last, 1); }
   }
   return true;
 }
@@ -452,8 +500,8 @@ inline bool read_cloud_soa(const std::string& path, CloudSoA& out, long& declare
 //   ASCII   the body is cut into `parts` byte ranges on token boundaries (the same cuts for every reader: they depend on the file
 //           only); a reader counts the tokens of its own range and `token_prefix(my_tokens, total_out)` -- the one exchange between the
 //           readers, provided by the caller -- returns the number of tokens in the ranges before it and the file's total.  Record r
-//           starts at token 9 r: the reader converts tokens [9 r0, 9 r1) for the records that begin in its range, reading the last
-//           record's tail out of the next range (at most 8 tokens) and leaving the head of a record begun earlier to its neighbour.
+//           starts at token P r (P = 9, or the declared properties when the fields are read by name): the reader converts tokens [P r0, P r1) for the records that begin in its range, reading the last
+//           record's tail out of the next range (fewer than P tokens) and leaving the head of a record begun earlier to its neighbour.
 // out.n = records of this part, `first_record` their global index, `total_records` the file's complete records (what
 // read_cloud_soa would deliver as out.n); record i of the part is global record first_record + i, field for field what
 // read_cloud_soa stores there.  alloc as in read_cloud_soa (five calls).  Returns false when the file cannot be opened, memory is
@@ -466,6 +514,7 @@ inline bool read_cloud_soa_part(const std::string& path, int part, int parts, Cl
   first_record = total_records = 0;
   if (parts < 1 || part < 0 || part >= parts || !map.open(path)) return false;
   const Header h = parse_header_full(map.begin(), map.end());
+  const CloudLayout L = cloud_layout(h);
   declared = h.vertex_count;
   auto allocate = [&](uint64_t n) -> bool {
     const uint64_t a = n ? n : 1;
@@ -492,10 +541,17 @@ inline bool read_cloud_soa_part(const std::string& path, int part, int parts, Cl
       const unsigned char* rec = reinterpret_cast<const unsigned char*>(h.body) + a * stride;
       for (uint64_t r = a; r < b; ++r, rec += stride) {
         const unsigned char* q = rec;
-        for (int f = 0; f < 9; ++f) {
-          double v = 0.0;
-          if (f < nprop) { v = detail::load_scalar(q, h.vsize[(size_t)f], h.vkind[(size_t)f]); q += h.vsize[(size_t)f]; }
-          detail::set_cloud_soa(out, r - r0, (unsigned)f, v);
+        if (L.named) {
+          for (int p = 0; p < L.P; ++p) {
+            if (L.fmap[(size_t)p] >= 0) detail::set_cloud_soa(out, r - r0, (unsigned)L.fmap[(size_t)p], detail::load_scalar(q, h.vsize[(size_t)p], h.vkind[(size_t)p]));
+            q += h.vsize[(size_t)p];
+          }
+        } else {
+          for (int f = 0; f < 9; ++f) {
+            double v = 0.0;
+            if (f < nprop) { v = detail::load_scalar(q, h.vsize[(size_t)f], h.vkind[(size_t)f]); q += h.vsize[(size_t)f]; }
+            detail::set_cloud_soa(out, r - r0, (unsigned)f, v);
+          }
         }
       }
     });
@@ -510,19 +566,24 @@ inline bool read_cloud_soa_part(const std::string& path, int part, int parts, Cl
   const auto first = detail::token_offsets(cuts);                                     // pass 1 over this part only
   uint64_t total_tokens = 0, g0 = 0;
   if (!token_prefix(first[(size_t)th], g0, total_tokens)) return false;
-  const uint64_t n = empty ? 0 : std::min<uint64_t>((uint64_t)declared, total_tokens / 9);
+  const uint64_t P = (uint64_t)L.P;                                                   // tokens per record (9, or the declared properties when read by name)
+  const uint64_t n = empty ? 0 : std::min<uint64_t>((uint64_t)declared, total_tokens / P);
   total_records = n;
   const uint64_t g1 = g0 + first[(size_t)th];
-  const uint64_t r0 = std::min<uint64_t>((g0 + 8) / 9, n), r1 = std::min<uint64_t>((g1 + 8) / 9, n);
+  const uint64_t r0 = std::min<uint64_t>((g0 + P - 1) / P, n), r1 = std::min<uint64_t>((g1 + P - 1) / P, n);
   first_record = r0;
   if (!allocate(r1 - r0)) return false;
   if (r1 == r0) return true;
-  const uint64_t lo = r0 * 9, hi = r1 * 9;                                            // the tokens this reader converts: [lo, hi)
+  const uint64_t lo = r0 * P, hi = r1 * P;                                            // the tokens this reader converts: [lo, hi)
+  auto put = [&](uint64_t g, const char* t, const char* e) {
+    const int fld = L.named ? L.fmap[(size_t)(g % P)] : (int)(g % P);
+    if (fld >= 0) detail::set_cloud_soa(out, g / P - r0, (unsigned)fld, detail::token_value(t, e));
+  };
   detail::run_parallel(th, [&](int i) {
     uint64_t g = g0 + first[(size_t)i];
     if (g >= hi) return;
     detail::for_each_token(cuts[(size_t)i], cuts[(size_t)i + 1], [&](const char* t, const char* e) {
-      if (g >= lo && g < hi) detail::set_cloud_soa(out, g / 9 - r0, (unsigned)(g % 9), detail::token_value(t, e));
+      if (g >= lo && g < hi) put(g, t, e);
       ++g;
     });
   });
@@ -534,7 +595,7 @@ inline bool read_cloud_soa_part(const std::string& path, int part, int parts, Cl
       if (p >= map.end()) break;                                                      // (cannot happen: n counts complete records only)
       const char* t = p;
       while (p < map.end() && !is_ws(*p)) ++p;
-      detail::set_cloud_soa(out, g / 9 - r0, (unsigned)(g % 9), detail::token_value(t, p));
+      put(g, t, p);
       ++g;
     }
   }

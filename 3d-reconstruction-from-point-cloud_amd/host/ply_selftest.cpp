@@ -1,6 +1,7 @@
 // Self-test of the PLY readers (host/ply_io.h, and the parallel host/ply_fast.h against it) on the grammar the reference accepts (reference
 // src/pointsTransfer.cpp:134-253, :266-455) and on malformed input.  Built with -fsanitize=address,undefined by the CPU
 // test-suite; exit code 0 = all good.
+#include <array>
 #include <cstdio>
 #include <algorithm>
 #include <fstream>
@@ -129,7 +130,7 @@ int main(int argc, char** argv) {
                             eq(got.nrm[3 * i + 1], (float)w.normal[1]) && eq(got.nrm[3 * i + 2], (float)w.normal[2]) &&
                             got.rgb[3 * i] == std::min(std::max(w.color[0], 0), 255) && got.rgb[3 * i + 1] == std::min(std::max(w.color[1], 0), 255) &&
                             got.rgb[3 * i + 2] == std::min(std::max(w.color[2], 0), 255);
-          if (!same) { CHECK(!"planar record differs"); break; }
+          if (!same) { std::printf("   planar mismatch in %s record %zu: got x %.9g y %.9g z %.9g n %.9g %.9g %.9g rgb %d %d %d\n", path.c_str(), i, got.x[i], got.y[i], got.z[i], got.nrm[3*i], got.nrm[3*i+1], got.nrm[3*i+2], got.rgb[3*i], got.rgb[3*i+1], got.rgb[3*i+2]); CHECK(!"planar record differs"); break; }
         }
         for (int c : seen) if (c != 1) { CHECK(!"a record was reported by the range callback zero or several times"); break; }
         // the same file read by `parts` cooperating readers (read_cloud_soa_part: what the ranks of pointsTransfer --gpus N do): the parts
@@ -199,6 +200,44 @@ int main(int argc, char** argv) {
         const float qual = 0.5f; b.append(reinterpret_cast<const char*>(&qual), 4); b.push_back((char)7);
       }
       soa_equals(write(dir, "bin_f.ply", b), want, (long)want.size(), true);
+    }
+    {   // fields BY NAME: the nine cloud fields declared under their usual names in another order, with other properties beside them -- text
+        // and binary -- give the records of the plain positional file; a header that only renames (nine properties, odd names) stays positional
+      std::mt19937_64 rg(99);
+      const int nrec = 5003;
+      std::vector<std::array<double, 9>> recs((size_t)nrec);
+      std::string pos = "ply\nformat ascii 1.0\nelement vertex " + std::to_string(nrec) + "\nend_header\n";
+      std::string hdr_named = "element vertex " + std::to_string(nrec) + "\nproperty float quality\nproperty uchar red\nproperty double z\nproperty double x\nproperty float nx\n"
+                              "property uchar alpha\nproperty double y\nproperty uchar green\nproperty float nz\nproperty float ny\nproperty uchar blue\nend_header\n";
+      std::string named = "ply\nformat ascii 1.0\n" + hdr_named, bin = "ply\nformat binary_little_endian 1.0\n" + hdr_named;
+      char num[64];
+      for (auto& r : recs) {
+        for (int f = 0; f < 6; ++f) r[(size_t)f] = (double)(int64_t)(rg() % 1600001 - 800000) * 0.125;     // (values text, float and double all hold exactly)
+        for (int f = 6; f < 9; ++f) r[(size_t)f] = (double)(rg() % 256);
+        for (int f = 0; f < 9; ++f) { std::snprintf(num, sizeof num, f < 6 ? "%.9g" : "%.0f", r[(size_t)f]); pos += num; pos += f == 8 ? "\n" : " "; }
+        const int order[11] = {-1, 6, 2, 0, 3, -2, 1, 7, 5, 4, 8};             // -1: quality, -2: alpha
+        for (int p = 0; p < 11; ++p) {
+          const int f = order[p];
+          if (f == -1) std::snprintf(num, sizeof num, "0.25"); else if (f == -2) std::snprintf(num, sizeof num, "255");
+          else std::snprintf(num, sizeof num, f < 6 ? "%.9g" : "%.0f", r[(size_t)f]);
+          named += num; named += p == 10 ? "\n" : (p % 3 ? " " : "\t");
+          if (f == -1) { const float v = 0.25f; bin.append(reinterpret_cast<const char*>(&v), 4); }
+          else if (f == -2) bin.push_back((char)255);
+          else if (f >= 6) bin.push_back((char)(unsigned char)r[(size_t)f]);
+          else if (f < 3) bin.append(reinterpret_cast<const char*>(&r[(size_t)f]), 8);
+          else { const float v = (float)r[(size_t)f]; bin.append(reinterpret_cast<const char*>(&v), 4); }
+        }
+      }
+      std::vector<Point> wantn;
+      long dn = 0;
+      CHECK(ply::read_cloud(write(dir, "pos9.ply", pos), wantn, dn) && wantn.size() == (size_t)nrec);
+      soa_equals(dir + "/pos9.ply", wantn, nrec, false);
+      soa_equals(write(dir, "named_a.ply", named), wantn, nrec, false);
+      soa_equals(write(dir, "named_b.ply", bin), wantn, nrec, false);
+      // nine properties with the usual names in the usual order, and nine with unknown names: positional, as ever
+      std::string odd = "ply\nformat ascii 1.0\nelement vertex " + std::to_string(nrec) + "\nproperty float a\nproperty float b\nproperty float c\nproperty float d\nproperty float e\n"
+                        "property float f\nproperty uchar g\nproperty uchar h\nproperty uchar i\nend_header\n" + pos.substr(pos.find("end_header\n") + 11);
+      soa_equals(write(dir, "odd9.ply", odd), wantn, nrec, false);
     }
     {   // binary mesh against the text mesh u.ply (cleaned of NaNs), faces with a quad in between (first three indices kept)
       ply::Mesh tm;

@@ -1047,6 +1047,43 @@ def _read_png_rgba(path):
     return raw[:, 1:].reshape(h, w, 4)
 
 
+def test_cli_reads_cloud_fields_by_name(tmp_path, pkg):
+    """A cloud file whose vertex element declares the nine fields under their usual names in ANOTHER order, with other properties beside
+    them (what scanner exports look like): the CLI takes the fields by name (host/ply_fast.h cloud_layout) and finds the neighbours it finds
+    in the plain positional file of the same points -- single process and through the --gpus 1 rank path."""
+    rng = np.random.default_rng(8)
+    n, m = 4000, 200
+    cloud = np.round(rng.random((n, 3)) * [3, 2, 1], 5); cn = np.round(rng.standard_normal((n, 3)), 4); crgb = rng.integers(0, 256, (n, 3))
+    verts = np.round(rng.random((m, 3)) * [3, 2, 1], 5)
+    hdr = "ply\nformat ascii 1.0\nelement vertex %d\n" % n
+    with open(tmp_path / "pos.ply", "w") as f:
+        f.write(hdr + "".join("property float %s\n" % p for p in ("x", "y", "z", "nx", "ny", "nz")) + "".join("property uchar %s\n" % p for p in ("red", "green", "blue")) + "end_header\n")
+        for p_, q_, c_ in zip(cloud, cn, crgb):
+            f.write("%.5f %.5f %.5f %.4f %.4f %.4f %d %d %d\n" % (*p_, *q_, *c_))
+    with open(tmp_path / "named.ply", "w") as f:
+        f.write(hdr + "property float scalar_intensity\nproperty uchar blue\nproperty float nz\nproperty double y\nproperty uchar red\nproperty double x\nproperty float ny\n"
+                "property uchar alpha\nproperty double z\nproperty float nx\nproperty uchar green\nend_header\n")
+        for p_, q_, c_ in zip(cloud, cn, crgb):
+            f.write("0.5 %d %.4f %.5f %d %.5f %.4f 255 %.5f %.4f %d\n" % (c_[2], q_[2], p_[1], c_[0], p_[0], q_[1], p_[2], q_[0], c_[1]))
+    with open(tmp_path / "mesh.ply", "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nelement face 1\nend_header\n" % m)
+        for v in verts:
+            f.write("%.5f %.5f %.5f 0 0 1 0.5 0.5 1 2 3\n" % tuple(v))
+        f.write("3 0 1 2\n")
+    exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "pointsTransfer")
+    outs = {}
+    for name, extra in (("pos", []), ("named", []), ("named_sharded", ["--gpus", "1"])):
+        d = tmp_path / name; d.mkdir()
+        r = subprocess.run([exe, str(tmp_path / ("pos.ply" if name == "pos" else "named.ply")), str(tmp_path / "mesh.ply"), "--resolution", "64", "--k", "8"] + extra,
+                           capture_output=True, text=True, cwd=d, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs[name] = open(d / "transfer.ply").read()
+    assert outs["pos"] == outs["named"]
+    rows = lambda t: np.array([[float(v) for v in l.split()] for l in t.split("end_header\n")[1].strip().splitlines()[:m]])
+    a, b = rows(outs["pos"]), rows(outs["named_sharded"])
+    assert np.abs(a[:, 8:] - b[:, 8:]).max() <= 1 and np.abs(a[:, :8] - b[:, :8]).max() <= 2e-5
+
+
 def _write_binary_plys(pc, mesh, src, rgb, verts, uv, vrgb, faces):
     """binary little-endian PLY files: cloud (double xyz, float normals, uchar colours), mesh (double x y z nx ny nz s t, int colours,
     list uchar int faces)"""
