@@ -21,7 +21,7 @@ SYMBOLS = [
     "pt_ctx_create", "pt_ctx_destroy", "pt_set_stream", "pt_set_param", "pt_last_error", "pt_stats", "pt_synchronize",
     "pt_build_aos", "pt_build_soa", "pt_build_soa_indexed", "pt_set_attributes", "pt_set_attributes_range", "pt_build_synth", "pt_rebuild",
     "pt_num_source", "pt_query_aos", "pt_query_soa", "pt_targets_synth", "pt_targets_soa", "pt_targets_aos", "pt_num_targets", "pt_query_resident", "pt_query_blend_resident",
-    "pt_resident_target_ids", "pt_resident_target_xyz", "pt_blend", "pt_blend_dev", "pt_blend_weighted", "pt_blend_weighted_dev", "pt_pca_normals",
+    "pt_resident_target_ids", "pt_resident_target_xyz", "pt_resident_source_xyz", "pt_blend", "pt_blend_dev", "pt_blend_weighted", "pt_blend_weighted_dev", "pt_pca_normals",
     "pt_pca_normals_dev", "pt_merge_candidates_dev", "pt_slab_need_dev", "pt_pack_requests_dev", "pt_query_bounded_dev",
     "pt_bake_texture", "pt_texture_pad", "pt_host_alloc", "pt_host_free", "pt_upload_begin", "pt_upload_range", "pt_upload_end", "pt_stream_query",
     "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_comm_abort", "pt_exchange_merge_dev", "pt_exchange_merge_local", "pt_query_exchange_blend",
@@ -40,6 +40,7 @@ class Stats(C.Structure):
         ("n_refine", C.c_int32), ("bbox_guess", C.c_int32), ("ms_bake", C.c_double),
         ("n_nodes", C.c_uint32), ("refine_levels", C.c_int32), ("max_cell_points", C.c_uint32), ("n_wave", C.c_uint32),
         ("pass1_pooled", C.c_int32), ("stream_skipped", C.c_int32), ("stream_revisited", C.c_int32), ("pass2_pooled", C.c_int32),
+        ("uniform_probe", C.c_int32), ("_pad2", C.c_int32),
     ]
 
 
@@ -94,6 +95,7 @@ def lib():
         "pt_query_blend_resident": (i32, [p, i32, i32, p, p, p, p]),
         "pt_resident_target_ids": (i32, [p, p]),
         "pt_resident_target_xyz": (i32, [p, p]),
+        "pt_resident_source_xyz": (i32, [p, p, C.POINTER(C.c_int)]),
         "pt_blend": (i32, [p, p, p, u64, i32, i32, p, p]),
         "pt_blend_dev": (i32, [p, p, p, u64, i32, i32, p, p]),
         "pt_blend_weighted": (i32, [p, p, p, u64, i32, p, p]),

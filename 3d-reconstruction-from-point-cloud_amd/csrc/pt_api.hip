@@ -63,6 +63,7 @@ struct pt_ctx {
   bool bbox_guess_ok = true;   // big clouds: lay the grid out from a sampled bounding box (cleared when a guess failed; reset by an upload)
   bool stream_bounds = true;   // pt_stream_query: later chunks are searched under the targets' current k-th distances and skipped when out of reach ("stream_bounds", a measurement switch)
   bool tile_bounds = false;    // run_query: bounds come with every target of the set (the tile kernel's bounded variant may take them)
+  bool uniform_known = false;  // ... or a 1/64 sample taken before this cloud's first sort has answered the question (pt_grid.hip, uniform_probe_kernel)
   bool pool2_ok = true, pool2 = true, uniform_seen = false;   // pass 2 without its histogram: allowed ("pool2"), not failed yet on this cloud, and the last build of
                                // this resident cloud found it uniform (reset by an upload together with pool_ok)
   bool pool_ok = true;         // big clouds, two-level sorts: pass 1 without its histogram pass (cleared when a bin outgrew its sampled region; reset by an upload)
@@ -319,6 +320,7 @@ int rebuild(pt_ctx* c) {
   // pass has been saved; otherwise the build is redone from the exact box and the context stops guessing for this cloud.
   bool guessed = false;
   c->st.bbox_guess = 0;
+  c->st.uniform_probe = 0;
   if (c->n) {
     guessed = c->bbox_guess_ok && c->n >= c->guess_min_points;
     { int r = source_bbox(c, guessed ? 1024u : 1u, mn, mx); if (r != PT_OK) return r; }
@@ -362,7 +364,26 @@ int rebuild(pt_ctx* c) {
     if (c->pool_ok && c->pool_min_points && c->n >= c->pool_min_points && nblocks > PT_MAXBINS && !pt_sort_group_shift(nblocks))
       pool_records = pt_sort_pool_records((uint32_t)c->n, nblocks / PT_MACRO_BLOCKS, (uint32_t)c->n_cu, recsize(c->src_type));
     // a resident cloud whose last build found it uniform (no refinement of the cell size, occupied cells at rho) takes pass 2 without its
-    // histogram too: block regions from the macro counts (pt_grid.hip, pool2_sizes_kernel); the pass-2 output then carries slack
+    // histogram too: block regions from the macro counts (pt_grid.hip, pool2_sizes_kernel); the pass-2 output then carries slack.
+    // A cloud nothing is known about yet (its FIRST build) is asked through a 1/64 sample, one short read-back (round 4: a detail-transfer
+    // run builds its index once -- reference src/pointsTransfer.cpp:259 -- so the first build is the one that counts)
+    if (!c->uniform_known && iter == 0 && force_h == 0.0 && c->pool2_ok && c->pool2 && c->adaptive && c->pool_min_points && c->n >= c->pool_min_points &&
+        nblocks > PT_MAXBINS && !pt_sort_group_shift(nblocks)) {
+      int olo[3], ohi[3];
+      for (int a = 0; a < 3; ++a) { olo[a] = pad_cells[a]; ohi[a] = c->gp.dim[a] - pad_cells[a]; }
+      uint32_t* pflag = (uint32_t*)c->counter.p + 15;
+      uint32_t* scratch = (uint32_t*)c->cell_start.p;                  // (written by finalize later; nblocks + nblocks / 512 words are a fraction of it)
+      if (c->in_half) { const __half* x = (const __half*)c->in_xyz.p; pt_launch_uniform_probe<__half>(c->gp, x, x + c->n, x + 2 * c->n, (uint32_t)c->n, olo, ohi, scratch, pflag, c->stream); }
+      else if (c->src_type == PT_F32) { const float* x = (const float*)c->in_xyz.p; pt_launch_uniform_probe<float>(c->gp, x, x + c->n, x + 2 * c->n, (uint32_t)c->n, olo, ohi, scratch, pflag, c->stream); }
+      else { const double* x = (const double*)c->in_xyz.p; pt_launch_uniform_probe<double>(c->gp, x, x + c->n, x + 2 * c->n, (uint32_t)c->n, olo, ohi, scratch, pflag, c->stream); }
+      HIPCHK(c, hipMemcpyAsync(c->h_counter + 11, pflag, 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->h_bbox + 6, scratch + pt_uniform_probe_acc_offset(nblocks), 16, hipMemcpyDeviceToHost, c->stream));     // (h_bbox: 8 pinned 64-bit words, 6 of them the box)
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      const double chi2 = (double)c->h_bbox[6] / 1024.0, dof = (double)c->h_bbox[7];
+      c->uniform_seen = c->h_counter[11] == 0 && dof > 0.0 && chi2 <= dof + 6.0 * std::sqrt(2.0 * dof) + 16.0;
+      c->uniform_known = true;
+      c->st.uniform_probe = c->uniform_seen ? 1 : -1;
+    }
     uint64_t pool2_records = 0;
     if (c->pool2_ok && c->pool2 && c->uniform_seen && nblocks > PT_MAXBINS && !pt_sort_group_shift(nblocks) && c->n)
       pool2_records = pt_sort_pool2_records(pool_records ? c->n + (uint64_t)(nblocks / PT_MACRO_BLOCKS) * c->n_cu * 128u : c->n, nblocks, recsize(c->src_type));
@@ -404,6 +425,7 @@ int rebuild(pt_ctx* c) {
         c->bbox_guess_ok = false;
         guessed = false;
         force_h = 0.0;
+        if (c->st.uniform_probe) { c->uniform_known = false; c->uniform_seen = false; }      // (the sample was binned on the wrong grid: asked again on the exact one)
         if (c->h_counter[15] & 1u) c->pool_ok = false;
         if (c->h_counter[15] & 2u) c->pool2_ok = false;
         --iter;
@@ -490,6 +512,7 @@ int rebuild(pt_ctx* c) {
   // the cell size is uniform enough for block regions sized from the macro counts (verified again by that build's overflow flag)
   c->uniform_seen = c->adaptive && c->n && c->st.n_refine == 0 && !c->grid_capped && c->st.rho_occupied > 0.0 &&
                     c->st.rho_occupied <= 1.25 * c->rho / (1.0 - std::exp(-c->rho));       // (a uniform cloud's occupied cells hold rho / (1 - e^-rho))
+  c->uniform_known = true;                                      // (what a finished build found outranks the sample)
   c->built = true;
   c->st.n_source = c->n;
   c->st.grid_dim[0] = c->gp.dim[0]; c->st.grid_dim[1] = c->gp.dim[1]; c->st.grid_dim[2] = c->gp.dim[2];
@@ -877,6 +900,9 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!strcmp(name, "refine_threshold")) { if (!(value >= 0 && value <= 1e9)) return fail(c, PT_ERR_ARG, "refine_threshold out of range"); c->refine_threshold = value; return PT_OK; }
   if (!strcmp(name, "pool2")) { c->pool2 = value != 0; c->pool2_ok = true; return PT_OK; }    // pass 2 without its histogram on clouds found uniform (1, default) or never (0)
   if (!strcmp(name, "stream_bounds")) { c->stream_bounds = value != 0; return PT_OK; }
+  // "forget": the next build of the resident cloud decides everything a FIRST build decides (sampled bounding box, pooled passes, uniformity
+  // sample, cell size) -- what bench.py times as its cold step, buffers already allocated
+  if (!strcmp(name, "forget")) { if (value != 0) { c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; } return PT_OK; }
   if (!strcmp(name, "pool_min_points")) { c->pool_min_points = value < 0 ? 0 : (uint64_t)value; c->pool_ok = true; return PT_OK; }   // pooled pass 1 from this size up (0: never)
   if (!strcmp(name, "guess_min_points")) { c->guess_min_points = value < 1 ? 1 : (uint64_t)value; return PT_OK; }   // sampled-bbox builds from this size up   // 0 group kernel only, 1 auto, 2 small tiles, 3 large tiles
   if (!strcmp(name, "own_stream")) { if (value != 0) c->stream = c->own_stream; return PT_OK; }
@@ -913,7 +939,7 @@ int pt_build_aos(pt_ctx* c, const pt_point* cloud, uint64_t n) {
   { int r = copy_in(c, c->aos_stage.p, cloud, n * sizeof(pt_point), 0); if (r) return r; }
   double* x = (double*)c->in_xyz.p;
   pt_launch_aos_split(c->aos_stage.p, (uint32_t)n, x, x + n, x + 2 * n, (Attr*)c->attr.p, c->stream);
-  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
+  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -936,7 +962,7 @@ int pt_build_soa_indexed(pt_ctx* c, const void* xyz, int xyz_type, const uint32_
   }
   c->src_type = xyz_type; c->n = n; c->has_gidx = gidx != nullptr; c->built = false;
   if (!gidx) { c->n_total = n; c->has_attr = false; }
-  c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
+  c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -1018,7 +1044,7 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
   else { double* x = (double*)c->in_xyz.p; pt_launch_synth_xyz<double>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream); }
   RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
   pt_launch_synth_attr(seed, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
-  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
+  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -1109,6 +1135,15 @@ int pt_resident_target_xyz(pt_ctx* c, void* xyz_dev) {
   if (!c || !xyz_dev) return PT_ERR_ARG;
   if (c->tgt_type < 0) return fail(c, PT_ERR_STATE, "no resident targets");
   HIPCHK(c, hipMemcpyAsync(xyz_dev, c->t_xyz.p, c->m * 3 * tsize(c->tgt_type), hipMemcpyDeviceToDevice, c->stream));
+  return finish(c);
+}
+
+int pt_resident_source_xyz(pt_ctx* c, void* xyz_dev, int* xyz_type_out) {
+  if (!c || !xyz_dev) return PT_ERR_ARG;
+  if (c->src_type < 0) return fail(c, PT_ERR_STATE, "no source cloud resident");
+  const size_t es = c->in_half ? sizeof(__half) : tsize(c->src_type);
+  HIPCHK(c, hipMemcpyAsync(xyz_dev, c->in_xyz.p, c->n * 3 * es, hipMemcpyDeviceToDevice, c->stream));
+  if (xyz_type_out) *xyz_type_out = c->in_half ? PT_F16 : c->src_type;
   return finish(c);
 }
 
@@ -1394,7 +1429,7 @@ int pt_upload_end(pt_ctx* c) {
   if (c->up_attr) pt_launch_pack_attr((const uint8_t*)c->up_rgb.p, (const float*)c->up_nrm.p, (uint32_t)n, (Attr*)c->attr.p, c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));                                // the caller's buffers are free again
   c->src_type = c->up_type; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = c->up_attr != 0; c->built = false;
-  c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
+  c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
   c->up_type = -1;
   release(c, c->up_rgb); release(c, c->up_nrm);
   return rebuild(c);
@@ -1471,7 +1506,7 @@ int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64
       const uint64_t f0 = ch * chunk_points, cnt = std::min<uint64_t>(chunk_points, n - f0);
       c->in_xyz = stage[b];
       c->src_type = xyz_type; c->n = cnt; c->n_total = cnt; c->has_gidx = false; c->has_attr = false; c->built = false;
-      c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
+      c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
     };
     auto bounds_and_reach = [&](uint64_t ch, int backward, uint32_t& reach) -> int {
       const double* mn = &boxes[(size_t)ch * 6];

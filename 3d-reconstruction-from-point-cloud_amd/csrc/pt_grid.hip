@@ -306,10 +306,16 @@ template <class Loader, int ITEMS, int SW>
 __global__ __launch_bounds__(SW) void scatter_kernel(Loader in, typename Loader::Rec* __restrict__ out, GridParams gp, BinSpec bs,
                                                      const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ tile_first, int nseg,
                                                      uint32_t* cursor, const uint32_t* __restrict__ seg_end = nullptr,
-                                                     const uint32_t* __restrict__ limit = nullptr, uint32_t* flag = nullptr, uint32_t scratch_base = 0) {
+                                                     const uint32_t* __restrict__ limit = nullptr, uint32_t* flag = nullptr, uint32_t scratch_base = 0,
+                                                     const uint32_t* abort_flag = nullptr) {
   using Rec = typename Loader::Rec;
   constexpr uint32_t TILE = SW * ITEMS;
   constexpr int BPT = PT_MAXBINS / SW;            // bins per thread in the scan
+  // A pooled pass 1 whose sampled regions overflowed (flag bit 1) leaves reserved-but-unwritten stretches inside its bins: whatever is
+  // there -- an earlier build's records, uninitialised memory -- must not be partitioned as if it were this build's (counts and
+  // placement would disagree, writes could leave their blocks).  Everything downstream of a failed guess returns at once; the host, which
+  // reads the flag in the read-back it makes anyway, redoes the build exactly.
+  if (abort_flag && (*abort_flag & 1u)) return;
   // seg_end != null: the input is what the pooled pass 1 wrote -- segments with slack between them and, inside them, the SENTINEL
   // records (id = PT_NOIDX_U) that pad the blocks a workgroup left partly filled; those are dropped here.
   const bool skip = seg_end != nullptr;
@@ -819,12 +825,65 @@ __global__ __launch_bounds__(WG) void pool2_counts_kernel(const uint32_t* __rest
   count[b] = b < nblocks ? min(cursor[b], rstart[b + 1]) - rstart[b] : 0u;
 }
 
+// Is the cloud uniform enough for those regions?  Round 3 only knew from a PREVIOUS build of the same resident cloud (finalize's occupancy);
+// round 4 asks a sample (about 4 M points) BEFORE the first sort: the sample's count per 8^3-cell block against what its macro block's sample count and
+// the block's share of the macro's occupied cells predict.  A uniform cloud keeps every block within 6 sigma of that (a 2048-point block
+// shows 32 +- 5.7 sample points); surfaces, clusters and anything with structure below the macro scale do not, by orders of magnitude.
+// The answer only CHOOSES the pass 2: the pooled one still verifies itself (flag bit 2) and is redone exactly if a block outgrows its region.
+template <class Loader>
+__global__ __launch_bounds__(WG) void uniform_probe_kernel(Loader in, GridParams gp, uint32_t n, uint32_t stride, uint32_t* __restrict__ blk_cnt) {
+  const uint64_t span = (uint64_t)stride * POOL_SAMPLE_RUN;
+  for (uint64_t i = (uint64_t)blockIdx.x * span + threadIdx.x; i < n; i += (uint64_t)gridDim.x * span) {
+    const uint32_t blk = block_of_rec(gp, in.load((uint32_t)i));
+    atomicAdd(&blk_cnt[blk], 1u);                       // (n / 64 atomics over nblocks addresses: ~30 per address)
+  }
+}
+// the macro blocks' sample counts = sums of their 512 blocks' (one atomic per sample point on <= 1024 addresses cost 4 ms at 1e9 points)
+__global__ __launch_bounds__(WG) void uniform_macro_kernel(const uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ macro_cnt) {
+  __shared__ uint32_t wsum[4];
+  const uint32_t v = blk_cnt[(size_t)blockIdx.x * PT_MACRO_BLOCKS + threadIdx.x] + blk_cnt[(size_t)blockIdx.x * PT_MACRO_BLOCKS + WG + threadIdx.x];
+  uint32_t tot;
+  (void)block_excl_scan(v, wsum, tot);
+  if (threadIdx.x == 0) macro_cnt[blockIdx.x] = tot;
+}
+// Two tests per block against e = (its macro block's sample count) x (its share of the macro's occupied cells): a MAXIMUM test -- more
+// than e + 6 sqrt(e) + 8 sample points is a clump -- and the block's term (s - e)^2 / e of a CHI-SQUARE sum over all blocks with e >= 4,
+// which is what sees smooth density gradients (a +-15 % drift across a macro block, enough to overflow the regions' 6-sigma slack, moves
+// a 32-point sample count by less than one sigma per block but the sum by tens of sigmas).  acc[0] += term * 1024 (fixed point), acc[1] += 1.
+__global__ __launch_bounds__(WG) void uniform_check_kernel(GridParams gp, OccBox ob, const uint32_t* __restrict__ macro_cnt, const uint32_t* __restrict__ blk_cnt,
+                                                           uint32_t nblocks, uint32_t* flag, unsigned long long* acc) {
+  const uint32_t b = blockIdx.x * WG + threadIdx.x;
+  float term = 0.f;
+  uint32_t used = 0;
+  if (b < nblocks) {
+  const uint32_t macro = b >> 9, m9 = b & 511u;
+  const int mx = (int)(macro % (uint32_t)gp.mdim[0]), my = (int)((macro / (uint32_t)gp.mdim[0]) % (uint32_t)gp.mdim[1]), mz = (int)(macro / (uint32_t)(gp.mdim[0] * gp.mdim[1]));
+  const int bx = mx * 8 + (int)((m9 & 1u) | ((m9 >> 2) & 2u) | ((m9 >> 4) & 4u));
+  const int by = my * 8 + (int)(((m9 >> 1) & 1u) | ((m9 >> 3) & 2u) | ((m9 >> 5) & 4u));
+  const int bz = mz * 8 + (int)(((m9 >> 2) & 1u) | ((m9 >> 4) & 2u) | ((m9 >> 6) & 4u));
+  auto inside = [](int lo, int len, int olo, int ohi) { return max(0, min(lo + len, ohi) - max(lo, olo)); };
+  const double cov_b = (double)inside(bx * 8, 8, ob.lo[0], ob.hi[0]) * inside(by * 8, 8, ob.lo[1], ob.hi[1]) * inside(bz * 8, 8, ob.lo[2], ob.hi[2]);
+  const double cov_m = (double)inside(mx * 64, 64, ob.lo[0], ob.hi[0]) * inside(my * 64, 64, ob.lo[1], ob.hi[1]) * inside(mz * 64, 64, ob.lo[2], ob.hi[2]);
+  const double e = cov_m > 0.0 ? (double)macro_cnt[macro] * cov_b / cov_m : 0.0;
+  const double sb = (double)blk_cnt[b];
+  if (sb > e + 6.0 * sqrt(e) + 8.0) atomicOr(flag, 1u);
+  if (e >= 4.0) { term = (float)((sb - e) * (sb - e) / e); used = 1; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { term += __shfl_xor(term, o); used += __shfl_xor(used, o); }
+  if ((threadIdx.x & 63) == 0 && used) {
+    atomicAdd(&acc[0], (unsigned long long)(term * 1024.0f + 0.5f));
+    atomicAdd(&acc[1], (unsigned long long)used);
+  }
+}
+
 // pass-2 histogram from the block ids pass 1 left beside the records: same tiling and flush as hist_kernel
 template <int ITEMS>
 __global__ __launch_bounds__(WG) void hist_bid_kernel(const uint16_t* __restrict__ bid, int nbins, const uint32_t* __restrict__ seg_start,
                                                       const uint32_t* __restrict__ tile_first, int nseg, uint32_t* counts, int tiles_per_wg,
-                                                      const uint32_t* __restrict__ seg_end = nullptr) {
+                                                      const uint32_t* __restrict__ seg_end = nullptr, const uint32_t* abort_flag = nullptr) {
   __shared__ uint32_t hist[PT_MACRO_BLOCKS];
+  if (abort_flag && (*abort_flag & 1u)) return;      // (pooled pass 1 overflowed: see scatter_kernel)
   constexpr uint32_t TILE = WG * ITEMS;
   int cur_seg = -1;
   for (int tt = 0; tt < tiles_per_wg; ++tt) {
@@ -879,8 +938,10 @@ __device__ inline void put_shadow(RecF* shadow, uint32_t pos, double x, double y
 template <class Rec>
 __global__ __launch_bounds__(FWG) void finalize_kernel(const Rec* __restrict__ in, Rec* __restrict__ out, GridParams gp,
                                                        const uint32_t* __restrict__ block_start, uint32_t* cell_start, uint32_t* occupied,
-                                                       RecF* __restrict__ shadow, const uint32_t* __restrict__ in_start = nullptr) {
+                                                       RecF* __restrict__ shadow, const uint32_t* __restrict__ in_start = nullptr,
+                                                       const uint32_t* abort_flag = nullptr) {
   constexpr int FSTAGE = 64 * 1024 / (int)sizeof(Rec);        // records of a block that fit the 64-KB output stage
+  if (abort_flag && *abort_flag) return;      // a pooled pass overflowed (either bit): this build's tables are void, the host redoes it (see scatter_kernel)
   static_assert(FSTAGE <= FWG * FITEMS, "staged blocks are register-resident blocks");
   __shared__ uint32_t cnt[PT_BLOCK_CELLS];
   __shared__ uint32_t wsum[FWG / 64];
@@ -1173,11 +1234,11 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
     ck(hipMemcpyAsync(tb.cursor2, tb.rstart, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s));
     mark(3);
     hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS_S, SW>), dim3(ntiles2), dim3(SW), 0, s, rl, tmp, gp, b2, tb.start1, tb.tile_first2,
-                       (int)nmacro, tb.cursor2, seg_end, tb.rstart, tb.pool_flag, scratch2);
+                       (int)nmacro, tb.cursor2, seg_end, tb.rstart, tb.pool_flag, scratch2, (const uint32_t*)tb.pool_flag);
     mark(4);
     hipLaunchKernelGGL(pool2_counts_kernel, dim3((nblocks + 1 + WG - 1) / WG), dim3(WG), 0, s, tb.rstart, tb.cursor2, nblocks, tb.block_count);
     pt_launch_scan_u32(tb.block_count, tb.block_start, nblocks + 1, tb.scan_tmp, s);
-    if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start, tb.occupied, tb.shadow32, tb.rstart);
+    if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start, tb.occupied, tb.shadow32, tb.rstart, (const uint32_t*)tb.pool_flag);
     mark(5);
   };
   const bool pool2 = tb.pool2_records && n && do_finalize;
@@ -1205,14 +1266,15 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
     if (pool2) { pooled_pass2(ntiles2, tb.cursor1); return done(out_final); }
     const int tpw = 4;
     hipLaunchKernelGGL((hist_bid_kernel<ITEMS>), dim3((ntiles2 + tpw - 1) / tpw), dim3(WG), 0, s, tb.bid, (int)PT_MACRO_BLOCKS, tb.start1,
-                       tb.tile_first2, (int)nmacro, tb.block_count, tpw, tb.cursor1);
+                       tb.tile_first2, (int)nmacro, tb.block_count, tpw, tb.cursor1, (const uint32_t*)tb.pool_flag);
     pt_launch_scan_u32(tb.block_count, tb.block_start, nblocks + 1, tb.scan_tmp, s);
     ck(hipMemcpyAsync(tb.cursor2, tb.block_start, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToDevice, s));
     mark(3);
     hipLaunchKernelGGL((scatter_kernel<RecLoader<Rec>, ITEMS_S, SW>), dim3(ntiles2), dim3(SW), 0, s, rl, tmp, gp, b2, tb.start1, tb.tile_first2,
-                       (int)nmacro, tb.cursor2, tb.cursor1);
+                       (int)nmacro, tb.cursor2, tb.cursor1, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (const uint32_t*)tb.pool_flag);
     mark(4);
-    if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start, tb.occupied, tb.shadow32);
+    if (do_finalize) hipLaunchKernelGGL(finalize_kernel<Rec>, dim3(nblocks), dim3(FWG), 0, s, (const Rec*)tmp, out_final, gp, tb.block_start, cell_start, tb.occupied, tb.shadow32,
+                                        (const uint32_t*)nullptr, (const uint32_t*)tb.pool_flag);
     mark(5);
     return done(do_finalize ? out_final : tmp);
   }
@@ -1267,6 +1329,33 @@ template const RecF* pt_launch_grid_sort<__half, RecF>(const GridParams&, const 
                                                       RecF*, uint32_t*, const SortTables&, bool, hipStream_t, uint64_t*);
 template const RecD* pt_launch_grid_sort<double, RecD>(const GridParams&, const double*, const double*, const double*, const uint32_t*, uint32_t,
                                                        RecD*, RecD*, uint32_t*, const SortTables&, bool, hipStream_t, uint64_t*);
+template <class T>
+void pt_launch_uniform_probe(const GridParams& gp, const T* x, const T* y, const T* z, uint32_t n, const int occ_lo[3], const int occ_hi[3],
+                             uint32_t* scratch, uint32_t* flag, hipStream_t s) {
+  const uint32_t nblocks = (uint32_t)gp.nblocks, nmacro = nblocks / PT_MACRO_BLOCKS;
+  uint32_t* blk_cnt = scratch;
+  uint32_t* macro_cnt = scratch + nblocks;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(scratch + pt_uniform_probe_acc_offset(nblocks));
+  (void)hipMemsetAsync(scratch, 0, sizeof(uint32_t) * ((size_t)pt_uniform_probe_acc_offset(nblocks) + 4), s);
+  (void)hipMemsetAsync(flag, 0, sizeof(uint32_t), s);
+  if (!n) return;
+  PlanarLoader<T> pl{x, y, z, nullptr};
+  // about 4 M sample points whatever the cloud's size (one run of 256 consecutive points in `stride` runs): the scattered atomics of a
+  // 1/64 sample of 1e9 points took 1.4 ms, and eight sample points per block still put a +-15 % density drift tens of sigmas out
+  const uint32_t stride = std::max<uint32_t>(16u, std::min<uint32_t>(256u, n >> 22));
+  const uint64_t runs = ((uint64_t)n + POOL_SAMPLE_RUN - 1) / POOL_SAMPLE_RUN;
+  const uint32_t gs = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((runs + stride - 1) / stride, 1), 4096);
+  hipLaunchKernelGGL((uniform_probe_kernel<PlanarLoader<T>>), dim3(gs), dim3(WG), 0, s, pl, gp, n, stride, blk_cnt);
+  static_assert(PT_MACRO_BLOCKS == 2 * WG, "two blocks per thread in the macro sums");
+  hipLaunchKernelGGL(uniform_macro_kernel, dim3(nmacro), dim3(WG), 0, s, blk_cnt, macro_cnt);
+  OccBox ob;
+  for (int a = 0; a < 3; ++a) { ob.lo[a] = occ_lo[a]; ob.hi[a] = occ_hi[a]; }
+  hipLaunchKernelGGL(uniform_check_kernel, dim3((nblocks + WG - 1) / WG), dim3(WG), 0, s, gp, ob, macro_cnt, blk_cnt, nblocks, flag, acc);
+}
+template void pt_launch_uniform_probe<float>(const GridParams&, const float*, const float*, const float*, uint32_t, const int*, const int*, uint32_t*, uint32_t*, hipStream_t);
+template void pt_launch_uniform_probe<__half>(const GridParams&, const __half*, const __half*, const __half*, uint32_t, const int*, const int*, uint32_t*, uint32_t*, hipStream_t);
+template void pt_launch_uniform_probe<double>(const GridParams&, const double*, const double*, const double*, uint32_t, const int*, const int*, uint32_t*, uint32_t*, hipStream_t);
+
 void pt_launch_sum_u32(const uint32_t* v, uint32_t n, uint32_t* out, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(sum_u32_kernel, dim3(std::min<uint32_t>((n + WG - 1) / WG, 64)), dim3(WG), 0, s, v, n, out);

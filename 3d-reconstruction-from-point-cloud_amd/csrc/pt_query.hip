@@ -690,7 +690,7 @@ struct WaveScan {
   uint32_t* pend_i;
   uint32_t npend;
 #ifdef PT_VISITS
-  uint32_t nv = 0, nn = 0;     // instrumented build: steps of 64 records, nodes entered
+  uint32_t nv = 0, nn = 0, nmerge = 0;     // instrumented build: steps of 64 records, nodes entered, sort-merges
 #endif
 
   __device__ void reset() { ld = INFINITY; li = PT_NOIDX_U; lim_d = bnd_d; lim_i = PT_NOIDX_U; npend = 0; set_lim32(); }
@@ -778,6 +778,9 @@ struct WaveScan {
     return KeyDI{ld_, li_};
   }
   __device__ __forceinline__ void merge64(double cd, uint32_t ci) {
+#ifdef PT_VISITS
+    ++nmerge;
+#endif
     const KeyDI r = merge_core(ld, li, cd, ci);
     ld = r.d; li = r.i;
   }
@@ -1010,6 +1013,7 @@ __global__ __launch_bounds__(WG, HIER ? PT_WV_MINW_H : PT_WV_MINW) void knn_wave
   const Rec tr = tgt[list ? list[wid] : wid];
 #ifdef PT_VISITS
   const unsigned long long pt_t0 = wall_clock64();
+  unsigned long long pt_ph[4] = {pt_t0, pt_t0, pt_t0, pt_t0};      // cells known / own cell done / ring-1 stream done / search done
 #endif
   __shared__ double pend_d[WG / 64][64];
   __shared__ uint32_t pend_i[WG / 64][64];
@@ -1072,6 +1076,9 @@ __global__ __launch_bounds__(WG, HIER ? PT_WV_MINW_H : PT_WV_MINW) void knn_wave
       const double gx = cgap(0, x, x), gy = cgap(1, y, y), gz = cgap(2, z, z);
       g2 = gx * gx + gy * gy + gz * gz;
     }
+#ifdef PT_VISITS
+    if (st < 0) { asm volatile("" ::"v"(S), "v"(E)); pt_ph[0] = wall_clock64(); }      // the 27 cells' table entries are here
+#endif
     // refined cells are descended into (one by one: the target's own first); everything else of this step is ONE stream, after the
     // own cell on the first step so that the bound it leaves decides which of the other 26 are read at all
     uint32_t nid = 0;
@@ -1082,9 +1089,15 @@ __global__ __launch_bounds__(WG, HIER ? PT_WV_MINW_H : PT_WV_MINW) void knn_wave
       else W.range(s0, e0);
       if (lane == 0) { S = E = 0; nid = 0; }
       W.flush();                                            // the limit the own cell leaves decides which of the other 26 are read
+#ifdef PT_VISITS
+      asm volatile("" ::"v"(W.ld)); pt_ph[1] = wall_clock64();
+#endif
     }
     const bool on = E > S && !(g2 * W.h2 > W.lim_d);
     W.stream(S, on && !nid ? E - S : 0u);
+#ifdef PT_VISITS
+    if (st < 0) { asm volatile("" ::"v"(W.ld)); pt_ph[2] = wall_clock64(); }
+#endif
     if constexpr (HIER) {
       unsigned long long want = __ballot(on && nid);
       while (want) {                                        // wave-uniform
@@ -1135,6 +1148,9 @@ __global__ __launch_bounds__(WG, HIER ? PT_WV_MINW_H : PT_WV_MINW) void knn_wave
     { const int side = 2 * rr + 1; nst = (side * side * side - (side - 2) * (side - 2) * (side - 2) + 63) / 64; }
   }
   W.flush();                                                // (the block sweep ends with candidates set aside)
+#ifdef PT_VISITS
+  asm volatile("" ::"v"(W.ld)); pt_ph[3] = wall_clock64();
+#endif
   if (lane < k) {
     const size_t row = (size_t)tr.id * (size_t)k;
     out_idx[row + lane] = W.li;
@@ -1173,6 +1189,10 @@ __global__ __launch_bounds__(WG, HIER ? PT_WV_MINW_H : PT_WV_MINW) void knn_wave
     const size_t row = (size_t)tr.id * (size_t)k;
     out_d2[row + k - 1] = (double)W.nv * 64.0; out_d2[row + k - 2] = (double)(wall_clock64() - pt_t0); out_d2[row + k - 3] = (double)pt_t0;
     out_d2[row + k - 4] = -(double)(W.nn + 1u);            // negative: a wave-kernel row, and how many nodes it entered (+1)
+    if (k >= 12) {                                          // phase times (tools/probe_wave_visits.py) and the number of sort-merges
+      out_d2[row + k - 5] = (double)(pt_ph[0] - pt_t0); out_d2[row + k - 6] = (double)(pt_ph[1] - pt_ph[0]); out_d2[row + k - 7] = (double)(pt_ph[2] - pt_ph[1]);
+      out_d2[row + k - 8] = (double)(pt_ph[3] - pt_ph[2]); out_d2[row + k - 9] = (double)(wall_clock64() - pt_ph[3]); out_d2[row + k - 10] = (double)W.nmerge;
+    }
   }
 #endif
 }

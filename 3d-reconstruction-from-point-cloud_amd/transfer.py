@@ -213,6 +213,13 @@ class PointsTransfer:
         self._adopt_torch_stream()
         self._chk(self._L.pt_resident_target_xyz(self._h, _ptr(xyz_dev)))
 
+    def resident_source_xyz_dev(self, xyz_dev):
+        """Planar xyz of the resident source cloud as kept on the device (fp16 clouds stay fp16); returns the element type."""
+        self._adopt_torch_stream()
+        t = C.c_int(-1)
+        self._chk(self._L.pt_resident_source_xyz(self._h, _ptr(xyz_dev), C.byref(t)))
+        return int(t.value)
+
     # -- blend / PCA ----------------------------------------------------------------------------
     def blend(self, idx, d2=None, mode=capi.BLEND_MEAN):
         idx = np.ascontiguousarray(idx, np.uint32)

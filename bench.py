@@ -42,28 +42,30 @@ KERNEL_NAMES = ["bbox_reduce", "pass1_histogram", "pass1_scatter", "pass2_histog
                 "target_sort", "knn_query"]
 
 
-def survey_alg_bytes(name, n, m, k, s=12):
+def survey_alg_bytes(name, n, m, k, s=12, pooled1=True, pooled2=True):
     """SURVEY.md 8(d)'s algorithmic bytes of the phase a kernel belongs to -- the figure `roofline.achieved` / `frac` are
     quoted on.  Query (k-NN + blend): N*s + M*s + M*k*16 + M*(4k + 24); build: N*(2s + 4), which 8(d) gives for the whole
-    build and which is split here over its data-moving passes in proportion to the bytes each must move."""
+    build and which is split here over its data-moving passes in proportion to the bytes each must move -- the passes that RAN
+    (pooled1 / pooled2: `pt_stats.pass1_pooled` / `pass2_pooled` of the timed steps): the exact pass 1 reads the cloud once more
+    for its histogram (12 B/point) where the pooled one reads a 1/64 sample, the exact pass 2 reads 2-byte block ids."""
     if name == "knn_query":
         return n * s + m * s + m * k * 16 + m * (4 * k + 24)
-    share = {"bbox_reduce": 0.0, "pass1_histogram": 0.2, "pass1_scatter": 28, "pass2_histogram_scan": 2, "pass2_scatter": 32, "finalize_cellsort": 32}
+    share = {"bbox_reduce": 0.0, "pass1_histogram": 0.2 if pooled1 else 12, "pass1_scatter": 28, "pass2_histogram_scan": 0.0 if pooled2 else 2, "pass2_scatter": 32, "finalize_cellsort": 32}
     if name in share:
         return n * (2 * s + 4) * share[name] / sum(share.values())
     return m * (2 * s + 4)            # target_sort: the same formula over the targets
 
 
-def kernel_alg_bytes(name, n, m, k, s=12):
+def kernel_alg_bytes(name, n, m, k, s=12, pooled1=True, pooled2=True):
     """The IMPLEMENTATION's own minimum for one launch of that kernel: inputs read once + outputs
     written once with the record sizes this build uses.  s = bytes per xyz (12 for fp32); records are s+4 (xyz + original
     index).  Reported as `impl_bytes_per_launch`, never as the roofline fraction."""
     rec = s + 4
     return {
         "bbox_reduce": n * s,
-        "pass1_histogram": n * s // 64,        # (the pooled pass 1 reads a 1/64 sample; the exact pass 1 of smaller clouds reads n * s)
+        "pass1_histogram": n * s // 64 if pooled1 else n * s,        # (the pooled pass 1 reads a 1/64 sample; the exact one the cloud)
         "pass1_scatter": n * (s + rec),
-        "pass2_histogram_scan": n * rec,
+        "pass2_histogram_scan": 0 if pooled2 else n * 2,             # (2-byte block ids; nothing when pass 2 is pooled)
         "pass2_scatter": n * 2 * rec,
         "finalize_cellsort": n * 2 * rec,
         "target_sort": m * (s + rec),
@@ -409,6 +411,7 @@ def main():
         pt.build_synth(n_total, seed, **gen)
         pt.targets_synth(m_total, seed, **gen)
     n_loc, m_loc = pt.num_source, pt.num_targets
+    st_first = pt.stats()          # the FIRST build of this cloud (allocation of every buffer included): what a one-shot run pays
     idx = torch.empty((m_loc, k), dtype=torch.int32, device=dev)
     d2 = torch.empty((m_loc, k), dtype=torch.float64, device=dev)
     rgb = torch.empty((m_loc, 3), dtype=torch.float32, device=dev)
@@ -422,6 +425,7 @@ def main():
     kms = [0.0] * 8
     phase = {"build": 0.0, "target_sort": 0.0, "knn_blend_fused": 0.0, "reblend_merged": 0.0}
     xstats = {}
+    flags = {}
 
     def reblend(rows):
         # targets whose neighbour lists were completed by other slabs: their fused blend is redone from the merged lists
@@ -456,6 +460,7 @@ def main():
             phase["knn_blend_fused"] += st["ms_query"]; phase["reblend_merged"] += pt.stats()["ms_blend"]
             xstats.update(xs)
             xstats["tile_leftover"] = st["n_leftover"]
+            flags.update({f: st[f] for f in ("pass1_pooled", "pass2_pooled", "uniform_probe", "bbox_guess")})
 
     def fence():
         torch.cuda.synchronize()
@@ -464,6 +469,14 @@ def main():
         torch.cuda.synchronize()
 
     box = BoxSampler(torch, local_rank)
+    # the first step after the first build: what a run that builds ONCE (reference src/pointsTransfer.cpp:259) pays for its search
+    torch.cuda.synchronize(); tq = time.perf_counter()
+    pt.query_blend_resident_dev(k, pkg.BLEND_MEAN, idx, d2, rgb, nrm)
+    torch.cuda.synchronize(); first_query_wall = (time.perf_counter() - tq) * 1e3
+    st_q = pt.stats()
+    first = {"first_build_ms": st_first["ms_build"], "first_build_kernels_ms": [round(v, 4) for v in st_first["ms_kernel"][:6]],
+             "first_query_ms": st_q["ms_sort_targets"] + st_q["ms_query"], "first_query_wall_ms": first_query_wall,
+             "first_build_flags": {f: st_first[f] for f in ("pass1_pooled", "pass2_pooled", "uniform_probe", "bbox_guess", "n_refine")}}
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -480,14 +493,31 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = m_total * args.steps / dt
+    # COLD steps (one GPU): every build forgets what earlier builds of this resident cloud learnt ("forget": sampled bounding box, pooled
+    # passes, uniformity sample, cell size are decided afresh, as on a first build) -- buffers stay allocated, so this is the first build's
+    # device work without hipMalloc.  `value` stays the warm figure (the contract's K timed steps); both are printed.
+    cold = None
+    if world == 1:
+        cs, cb = [], []
+        for _ in range(3):
+            torch.cuda.synchronize(); tc = time.perf_counter()
+            pt.set_param("forget", 1)
+            pt.rebuild()
+            pt.query_blend_resident_dev(k, pkg.BLEND_MEAN, idx, d2, rgb, nrm)
+            torch.cuda.synchronize(); cs.append((time.perf_counter() - tc) * 1e3)
+            stc = pt.stats(); cb.append(stc["ms_build"])
+        cold = dict(first, cold_step_ms=round(sum(cs) / len(cs), 4), cold_build_ms=round(sum(cb) / len(cb), 4),
+                    cold_flags={f: stc[f] for f in ("pass1_pooled", "pass2_pooled", "uniform_probe", "bbox_guess")},
+                    note="cold_step = forget + rebuild + query on allocated buffers (wall, mean of 3); first_build_ms includes every hipMalloc of the first build")
 
     if rank == 0:
         K = args.steps
         kavg = [v / K for v in kms]
         dom = max(range(8), key=lambda i: kavg[i])
         sx = 6 if type_name == "f16" else 12                                  # s = bytes per xyz (fp16 clouds: 6)
-        alg = survey_alg_bytes(KERNEL_NAMES[dom], n_loc, m_loc, k, sx)      # what frac is quoted on
-        impl = kernel_alg_bytes(KERNEL_NAMES[dom], n_loc, m_loc, k)        # this build's own minimum (its sorted records are fp32 either way), for comparison only
+        p1, p2 = flags.get("pass1_pooled", 0) == 1, flags.get("pass2_pooled", 0) == 1      # which passes the timed steps ran (the byte model follows them)
+        alg = survey_alg_bytes(KERNEL_NAMES[dom], n_loc, m_loc, k, sx, p1, p2)      # what frac is quoted on
+        impl = kernel_alg_bytes(KERNEL_NAMES[dom], n_loc, m_loc, k, 12, p1, p2)     # this build's own minimum (its sorted records are fp32 either way), for comparison only
         achieved = alg / (kavg[dom] * 1e-3) / 1e9
         _, pmc_file = pmc_profile(args.workload, world)
         b_alg_job = n_total * (2 * sx + 4) + (n_total * sx + m_total * sx + m_total * k * 16 + m_total * (4 * k + 24))   # B_build + B_query
@@ -511,6 +541,8 @@ def main():
                              # HBM bytes every kernel of one step actually moved (same PMC passes, summed over the step's dispatches)
                              "traffic_per_step": pmc_traffic("__step__", args.workload, world)},
             "kernels_ms": dict(zip(KERNEL_NAMES, [round(v, 4) for v in kavg])),
+            "build_flags": flags,      # of the timed (warm) steps: 1 = that pass ran without its histogram; uniform_probe 0 = a previous build already knew
+            "cold": cold,
             "phases_ms": {a: round(b / K, 4) for a, b in phase.items()},
             "rank0": {"n_source": n_loc, "n_target": m_loc, "exchange": xstats},
             # the state of rank 0's GPU over the timed steps (sysfs, sampled by a host thread) and what the pass-1 scatter -- the kernel

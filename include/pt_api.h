@@ -97,7 +97,11 @@ typedef struct pt_stats_t {
   int32_t stream_skipped;   /* last pt_stream_query: (chunk, forward sweep) steps it did not search because no target's bound reached the chunk's box */
   int32_t stream_revisited; /* ... and chunks its backward sweep brought back for targets that lay outside them before they had a list */
   int32_t pass2_pooled;     /* last build: 1 pass 2 took its block regions from the macro counts (no pass-2 histogram: a rebuild of a resident cloud the
-                             * previous build found uniform); -1 a block outgrew its region and the build was redone exactly; 0 exact pass 2 */
+                             * previous build found uniform, or -- round 4 -- a first build whose 1/64 sample said so); -1 a block outgrew its region and
+                             * the build was redone exactly; 0 exact pass 2 */
+  int32_t uniform_probe;    /* last build: 1 a 1/64 sample taken before the sort found the cloud uniform (pooled pass 2 on a FIRST build), -1 it did
+                             * not, 0 not asked (small cloud, one- or three-level grid, or a previous build of this cloud already knew) */
+  int32_t _pad2;
 } pt_stats_t;
 
 /* ---- context ------------------------------------------------------------------------ */
@@ -195,6 +199,9 @@ int  pt_query_blend_resident(pt_ctx*, int k, int blend_mode, uint32_t* idx_dev, 
 int  pt_resident_target_ids(pt_ctx*, uint32_t* ids_dev);
 /* Planar xyz (f32 or f64 as generated) of the resident targets, copied to a device buffer. */
 int  pt_resident_target_xyz(pt_ctx*, void* xyz_dev);
+/* Planar xyz of the resident SOURCE cloud as it is kept (f32, f64, or f16 for clouds built from PT_F16), copied to a device buffer of
+ * 3 * pt_num_source values; *xyz_type_out (may be null) receives the element type.  Tests and probes read generated clouds with it. */
+int  pt_resident_source_xyz(pt_ctx*, void* xyz_dev, int* xyz_type_out);
 
 /* ---- blend: the only blend arithmetic of the reference is pointsTransfer.cpp:95-97 --------- */
 /* host buffers in / out */

@@ -688,7 +688,9 @@ def test_pooled_pass2_on_a_uniform_cloud(pkg, oracle, f64, pool1, slab):
             p.set_param("pool_min_points", 1)
         p.build(src, gidx=gidx)
         st = p.stats()
-        assert st["n_levels"] == 2 and st["pass2_pooled"] == 0 and st["pass1_pooled"] == (1 if pool1 else 0), st
+        # (round 4: a cloud big enough for the pooled pass 1 -- "pool_min_points", lowered here -- is asked through a 1/64 sample BEFORE its
+        #  first sort and pools pass 2 on that FIRST build; smaller clouds learn it from their first build's occupancy, as before)
+        assert st["n_levels"] == 2 and st["pass2_pooled"] == (1 if pool1 else 0) and st["uniform_probe"] == (1 if pool1 else 0) and st["pass1_pooled"] == (1 if pool1 else 0), st
         i0, d0 = p.query(tgt, k)
         p.rebuild()
         st = p.stats()
@@ -731,17 +733,79 @@ def test_pooled_pass2_overflow_falls_back(pkg, oracle):
     assert np.array_equal(idx, wi) and np.array_equal(d2, wd)
 
 
-def test_pooled_pass1_overflow_falls_back_to_the_exact_histogram(pkg, oracle):
+def test_uniformity_sample_decides_the_first_build(pkg, oracle):
+    """What the 1/64 sample taken before a cloud's FIRST sort says (pt_stats.uniform_probe) and what the build does with it: a uniform cloud
+    pools pass 2 at once; a smooth density gradient -- no block far off, the chi-square sum is -- and a clump are refused (exact pass 2, no
+    build wasted on a region that overflows); "forget" makes a rebuild ask again.  Same neighbours as the oracle every time."""
+    rng = np.random.default_rng(93)
+    n, m, k = 3_000_000, 3000, 8
+    uni = rng.random((3, n), dtype=np.float32)
+    grad = uni.copy(); grad[0] = (0.15 + 0.85 * grad[0]) ** 2.0                 # density ~ 1 / sqrt(x): 2.6 x across the cloud, every cell occupied
+    clump = uni.copy(); clump[:, : n // 50] = (0.4 + 0.01 * rng.random((3, n // 50))).astype(np.float32)
+    tgt = rng.random((3, m), dtype=np.float32)
+    for name, src, want_probe in (("uniform", uni, 1), ("gradient", grad, -1), ("clump", clump, -1)):
+        with pkg.PointsTransfer(device=0, k_hint=k) as p:
+            p.set_param("pool_min_points", 1)
+            p.build(src)
+            st = p.stats()
+            assert st["n_levels"] == 2 and st["uniform_probe"] == want_probe, (name, st)
+            assert st["pass2_pooled"] == (1 if want_probe == 1 else 0), (name, st)          # never -1: the sample kept the overflow from happening
+            got = p.query(tgt, k)
+            p.rebuild()
+            assert p.stats()["uniform_probe"] == 0, name                                    # a finished build knows: no second sample
+            p.set_param("forget", 1)
+            p.rebuild()
+            assert p.stats()["uniform_probe"] == want_probe, name
+            got2 = p.query(tgt, k)
+        want = oracle.KdTree(src).query(tgt, k)
+        _check_exact(got, want, name)
+        _check_exact(got2, want, name + " after forget")
+
+
+def test_wrong_sampled_box_and_pool_overflow_in_one_build(pkg, oracle):
+    """Two guesses of one build fail together: the sampled bounding box misses an outlier AND the pooled pass 1's sampled bin regions
+    overflow (every point outside the sampled runs sits in one clump).  rebuild() restarts itself once per failed guess; the result is
+    the exact build's, and the context remembers both failures."""
+    rng = np.random.default_rng(94)
+    n, m, k = 3_000_000, 3000, 8
+    src = rng.random((3, n), dtype=np.float32)
+    run = np.arange(n) // 256
+    hidden = (run % 64) != 0                                  # the pooled pass 1 samples one run of 256 in 64 ...
+    src[:, hidden] = (0.25 + 0.01 * rng.random((3, int(hidden.sum())))).astype(np.float32)
+    src[:, 300] = (3.0, -2.0, 7.5)                           # ... and the bounding box one run in 1024: this point is in neither sample
+    tgt = np.concatenate([rng.random((3, m // 2), dtype=np.float32), (0.25 + 0.01 * rng.random((3, m - m // 2))).astype(np.float32),
+                          np.array([[2.9], [-1.9], [7.4]], np.float32)], axis=1)
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.set_param("pool_min_points", 1)
+        p.set_param("guess_min_points", 100000)
+        p.set_param("adaptive", 0)
+        p.build(src)
+        st = p.stats()
+        assert st["bbox_guess"] == -1, st
+        got = p.query(tgt, k)
+        p.rebuild()
+        st2 = p.stats()
+        assert st2["bbox_guess"] == 0 and st2["pass1_pooled"] in (0, 1), st2
+        got2 = p.query(tgt, k)
+    want = oracle.KdTree(src).query(tgt, k)
+    _check_exact(got, want, "both guesses failed")
+    _check_exact(got2, want, "rebuild after both failures")
+
+
+@pytest.mark.parametrize("at", [0.25, 0.985])
+def test_pooled_pass1_overflow_falls_back_to_the_exact_histogram(pkg, oracle, at):
     """A cloud built to fool the sample: the runs the sample reads (one run of 256 points in 64) are uniform, every other point sits in
     one small clump.  The clump's bin outgrows the region its sample gave it, the flag is raised, and the build is redone with the
-    exact pass 1 -- same answer as the oracle, and the context stops pooling for this cloud."""
+    exact pass 1 -- same answer as the oracle, and the context stops pooling for this cloud.  at = 0.985: the clump sits in the LAST
+    macro block, whose region ends where the records array does (the passes downstream of a failed guess must not touch the
+    reserved-but-unwritten stretch, let alone write past the allocation: they return at once, pt_grid.hip scatter_kernel)."""
     rng = np.random.default_rng(5)
     n, m, k = 3_000_000, 3000, 8
     src = rng.random((3, n), dtype=np.float32)
     run = np.arange(n) // 256
     hidden = (run % 64) != 0
-    src[:, hidden] = (0.25 + 0.01 * rng.random((3, int(hidden.sum())))).astype(np.float32)
-    tgt = np.concatenate([rng.random((3, m // 2), dtype=np.float32), (0.25 + 0.01 * rng.random((3, m - m // 2))).astype(np.float32)], axis=1)
+    src[:, hidden] = (at + 0.01 * rng.random((3, int(hidden.sum())))).astype(np.float32)
+    tgt = np.concatenate([rng.random((3, m // 2), dtype=np.float32), (at + 0.01 * rng.random((3, m - m // 2))).astype(np.float32)], axis=1)
     with pkg.PointsTransfer(device=0, k_hint=k) as p:
         p.set_param("pool_min_points", 1)
         p.set_param("adaptive", 0)                         # (keep the coarse grid of the bounding box: the clump stays in one macro bin)

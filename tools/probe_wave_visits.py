@@ -28,6 +28,8 @@ def target_class(m, n):
     return np.where(t < 70, 0, np.where(t < 95, 1, 2))
 with pkg.PointsTransfer(device=0, k_hint=k) as p:
     p.set_param("refine_threshold", thr)
+    for a in sys.argv[5:]:
+        p.set_param(a.split("=")[0], float(a.split("=")[1]))
     p.build_synth(n, seed, dist=pkg.capi.DIST_CLUSTERED, xyz_type=xt); p.targets_synth(m, seed, dist=pkg.capi.DIST_CLUSTERED, xyz_type=xt)
     idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
     for it in range(2):
@@ -36,6 +38,8 @@ with pkg.PointsTransfer(device=0, k_hint=k) as p:
     print("n %d m %d k %d thr %d: query %.1f ms, wave targets %d, nodes %d" % (n, m, k, thr, dt * 1e3, st["n_wave"], st["n_nodes"]))
     v = d2[:, k - 1].cpu().numpy(); du = d2[:, k - 2].cpu().numpy() / 100.0; t0 = d2[:, k - 3].cpu().numpy(); tag = d2[:, k - 4].cpu().numpy()
     cls = target_class(m, n)
+    ph = [d2[:, k - 5 - j].cpu().numpy() / 100.0 for j in range(5)] if k >= 12 else None
+    nmg = d2[:, k - 10].cpu().numpy() if k >= 12 else None
     wave = tag < 0
     nodes = np.where(wave, -tag - 1, 0)
     for name, sel in (("wave, no node", wave & (nodes == 0)), ("wave, descending", wave & (nodes > 0))):
@@ -46,6 +50,9 @@ with pkg.PointsTransfer(device=0, k_hint=k) as p:
                nodes[sel].mean(), nodes[sel].max(), ((t0[sel] + du[sel] * 100).max() - t0[sel].min()) / 1e5))
         for c, cn in enumerate(("sheet", "blob", "background")):
             w = sel & (cls == c)
+            if w.any() and ph is not None:
+                print("    %-10s phases us: lookup %.1f | own cell %.1f | ring-1 stream %.1f | rings>1 + flush %.1f | output + blend %.1f | merges %.1f" %
+                      ((cn,) + tuple(p_[w].mean() for p_ in ph) + (nmg[w].mean(),)))
             if w.any():
                 print("    %-10s %9d targets, records mean %.0f, time mean %.1f us (%.1f %% of this kernel's wave time), us per 1000 records %.2f" %
                       (cn, w.sum(), v[w].mean(), du[w].mean(), 100 * du[w].sum() / du[sel].sum(), du[w].sum() / (v[w].sum() / 1000)))

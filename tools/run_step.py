@@ -5,12 +5,16 @@ sys.path.insert(0, '.')
 import torch
 import __graft_entry__ as g
 pkg = g.load_package()
-cfgs = {"C2": (10_000_000, 1_000_000, 8, 0xC2), "C3": (100_000_000, 10_000_000, 16, 0xC3), "C4": (1_000_000_000, 50_000_000, 8, 0xC4)}
+cfgs = {"C2": (10_000_000, 1_000_000, 8, 0xC2), "C3": (100_000_000, 10_000_000, 16, 0xC3), "C4": (1_000_000_000, 50_000_000, 8, 0xC4),
+        "C5": (1_000_000_000, 50_000_000, 32, 0xC5)}
 name = sys.argv[1] if len(sys.argv) > 1 else "C4"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 n, m, k, seed = cfgs[name]
 with pkg.PointsTransfer(device=0, k_hint=k) as p:
-    p.build_synth(n, seed); p.targets_synth(m, seed)
+    gen = dict(dist=pkg.capi.DIST_CLUSTERED, xyz_type=pkg.F16) if name == "C5" else {}
+    for a in sys.argv[3:]:                      # name=value pairs for pt_set_param (probes)
+        p.set_param(a.split("=")[0], float(a.split("=")[1]))
+    p.build_synth(n, seed, **gen); p.targets_synth(m, seed, **gen)
     idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
     rgb = torch.empty((m, 3), dtype=torch.float32, device="cuda"); nrm = torch.empty((m, 3), dtype=torch.float32, device="cuda")
     for it in range(steps):
