@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <string>
 #include <vector>
@@ -406,13 +407,20 @@ int rebuild(pt_ctx* c) {
     uint64_t* bv = verify ? (uint64_t*)c->bbox6.p : nullptr;
     { const int r = c->in_half ? run_source_sort<__half, RecF>(c, bv) : (c->src_type == PT_F32 ? run_source_sort<float, RecF>(c, bv) : run_source_sort<double, RecD>(c, bv)); if (r != PT_OK) return r; }
     c->h_counter[15] = 0;
-    if (pool_records || pool2_records) {   // did every bin stay inside the region its estimate gave it?  (read with the bounding box below when there is one)
-      HIPCHK(c, hipMemcpyAsync(c->h_counter + 15, c->stb.pool_flag, 4, hipMemcpyDeviceToHost, c->stream));
-      if (!verify) HIPCHK(c, hipStreamSynchronize(c->stream));
+    // ONE read-back per sort (round 4; there were up to three, each a drained pipeline -- a third of a 10 M-point rebuild): the pooled
+    // passes' overflow flag, the verified bounding box and finalize's occupancy travel together; the occupancy sum is queued before it is
+    // known whether a guess failed (then it sums whatever an aborted finalize left and is not looked at)
+    const bool want_occ = c->adaptive && c->n;
+    if (want_occ) {
+      HIPCHK(c, hipMemsetAsync(occ, 0, 8, c->stream));
+      pt_launch_sum_u32(c->stb.block_count, nblocks, occ, c->stream);
+      HIPCHK(c, hipMemcpyAsync(c->h_counter + 8, occ, 8, hipMemcpyDeviceToHost, c->stream));
     }
+    if (pool_records || pool2_records)     // did every bin stay inside the region its estimate gave it?
+      HIPCHK(c, hipMemcpyAsync(c->h_counter + 15, c->stb.pool_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    if (verify) HIPCHK(c, hipMemcpyAsync(c->h_bbox, c->bbox6.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (want_occ || pool_records || pool2_records || verify) HIPCHK(c, hipStreamSynchronize(c->stream));
     if (verify) {
-      HIPCHK(c, hipMemcpyAsync(c->h_bbox, c->bbox6.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
       bool inside = true, finite = true;
       for (int a = 0; a < 3; ++a) {
         mn[a] = pt_bbox_decode(c->h_bbox[a]); mx[a] = pt_bbox_decode(c->h_bbox[3 + a]);      // exact from here on
@@ -440,11 +448,7 @@ int rebuild(pt_ctx* c) {
       continue;
     }
     c->st.rho_occupied = 0.0;
-    if (!c->adaptive || !c->n) break;
-    HIPCHK(c, hipMemsetAsync(occ, 0, 8, c->stream));
-    pt_launch_sum_u32(c->stb.block_count, nblocks, occ, c->stream);
-    HIPCHK(c, hipMemcpyAsync(c->h_counter + 8, occ, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!want_occ) break;
     const double occupied = std::max<double>(1.0, c->h_counter[8]);
     max_cell = c->h_counter[9];
     c->st.rho_occupied = (double)c->n / occupied;
@@ -590,6 +594,9 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
   // The tile kernel over all blocks (+ the large geometry for the blocks the small one had to pass on); what it cannot
   // settle is on the todo list afterwards.  fp64 clouds: the LDS image is the fp32 shadow of the sorted records, the exact
   // 32-byte records are fetched for the few candidates that reach the ranking pass.
+  std::function<void()> retry_launch;                   // the large-geometry launch over the blocks the small one passed on
+  bool retry_pending = false;                           // ... its block count is still on its way to the host (see group_f32 / group_f64)
+  const bool defer_retry = c->wave_min > 0 && c->wave_min <= 1 && c->n_nodes == 0 && (k > 16 || c->sync) && k <= 64;      // the leftovers get a wave each, sized by a read-back
   auto tile_launches = [&](const RecF* src32, const RecF* tgt32, const RecD* src64, const RecD* tgt64, uint32_t* todo_n) -> int {
     const double cells = (double)c->gp.dim[0] * c->gp.dim[1] * c->gp.dim[2];
     // regions (10^3 cells) that fit the small capacity with headroom run the two-workgroups-per-CU geometry
@@ -606,12 +613,18 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
                        tile_small, battr, (uint32_t)c->n_total, br ? br->mode : 0, br ? br->rgb_out : nullptr, br ? br->nrm_out : nullptr, nullptr, 0,
                        second_chance ? (uint32_t*)c->retry.p : nullptr, retry_n, src64, tgt64, c->e_src, c->stream, bound2_dev);
     if (second_chance) {
-      HIPCHK(c, hipMemcpyAsync(c->h_counter + 5, retry_n, 4, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));            // (one short read-back; usually 0 blocks and no launch)
-      if (c->h_counter[5])
+      retry_launch = [=]() {
         pt_launch_knn_tile(c->gp, src32, (const uint32_t*)c->cell_start.p, tgt32, c->ttb.block_start, k, idx_dev, d2_dev, (uint32_t*)c->todo.p, todo_n,
                            0, battr, (uint32_t)c->n_total, br ? br->mode : 0, br ? br->rgb_out : nullptr, br ? br->nrm_out : nullptr,
                            (const uint32_t*)c->retry.p, c->h_counter[5], nullptr, nullptr, src64, tgt64, c->e_src, c->stream, bound2_dev);
+      };
+      HIPCHK(c, hipMemcpyAsync(c->h_counter + 5, retry_n, 4, hipMemcpyDeviceToHost, c->stream));
+      // (round 4) when the leftover pass reads the todo list's length anyway -- one wave per leftover target -- the two counts share that
+      // read-back: a 1 M-target query spent a third of its time in two drained pipelines.  Otherwise: one short read-back here; usually
+      // 0 blocks and no launch
+      if (defer_retry) { retry_pending = true; return PT_OK; }
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (c->h_counter[5]) retry_launch();
     }
     return PT_OK;
   };
@@ -661,6 +674,13 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
         uint32_t cnt = m;
         if (list) {                                           // a device-side list (what the tile kernel left over): its length sizes the launch
           if (hipMemcpyAsync(c->h_counter + 14, list_n, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return;
+          if (retry_pending) {                                // the second-chance blocks' count came with it: their launch may add to the list
+            retry_pending = false;
+            if (c->h_counter[5]) {
+              retry_launch();
+              if (hipMemcpyAsync(c->h_counter + 14, list_n, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return;
+            }
+          }
           cnt = c->h_counter[14];
         }
         c->st.n_wave = cnt;
@@ -699,6 +719,13 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
         uint32_t cnt = m;
         if (list) {                                           // a device-side list (what the tile kernel left over): its length sizes the launch
           if (hipMemcpyAsync(c->h_counter + 14, list_n, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return;
+          if (retry_pending) {                                // the second-chance blocks' count came with it: their launch may add to the list
+            retry_pending = false;
+            if (c->h_counter[5]) {
+              retry_launch();
+              if (hipMemcpyAsync(c->h_counter + 14, list_n, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return;
+            }
+          }
           cnt = c->h_counter[14];
         }
         c->st.n_wave = cnt;
