@@ -589,7 +589,9 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
   const bool h2_ok = h2d <= 3.0e38 && h2d >= 1.2e-38;
   // radius-bounded queries run the group kernel (few targets, scattered: the slab exchange) -- unless the caller says the bounds come with
   // EVERY target of a block-sorted set (pt_stream_query from its second chunk on): then the tile kernel's bounded variant takes them
-  const bool tile_bounded = bound2_dev && c->tile_bounds && ttype == PT_F32 && !br && k <= 24;
+  // (round 4: fp64 clouds and k in 25..32 as well -- ADVICE r3: since every chunk of a streamed cloud brings bounds, those went to the
+  //  8-lane group kernel in EVERY chunk, the first, unbounded one included)
+  const bool tile_bounded = bound2_dev && c->tile_bounds && !br && k <= PT_TILE_MAX_K;
   const bool use_tile = c->tile && !contrast && (!bound2_dev || tile_bounded) && m && k <= PT_TILE_MAX_K && h2_ok && (ttype == PT_F32 || c->rec32_valid);
   // The tile kernel over all blocks (+ the large geometry for the blocks the small one had to pass on); what it cannot
   // settle is on the todo list afterwards.  fp64 clouds: the LDS image is the fp32 shadow of the sorted records, the exact
@@ -779,7 +781,7 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (use_tile) {
       { int r = tile_launches((const RecF*)c->rec32.p, nullptr, (const RecD*)c->rec.p, tsorted, todo_n); if (r != PT_OK) return r; }
-      group_f64(tsorted, nullptr, (const uint32_t*)c->todo.p, todo_n);
+      group_f64(tsorted, bound2_dev, (const uint32_t*)c->todo.p, todo_n);       // (what the tile kernel left over keeps its bound, if it came with one)
       if (br && !wave_blended)
         pt_launch_blend_list<RecD>((const uint32_t*)c->todo.p, todo_n, m, tsorted, idx_dev, d2_dev, k, br->mode, (const Attr*)c->attr.p,
                                    (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
@@ -1148,6 +1150,31 @@ int pt_query_blend_resident(pt_ctx* c, int k, int mode, uint32_t* idx_dev, doubl
   const BlendReq br{mode, rgb_out_dev, nrm_out_dev};
   c->st.ms_blend = 0.f;          // part of ms_query here
   return run_query(c, c->t_xyz.p, c->tgt_type, c->m, k, nullptr, idx_dev, d2_dev_or_null, &br);
+}
+
+int pt_query_resident_host(pt_ctx* c, int k, int blend_mode, uint32_t* idx_out, double* d2_out, float* rgb_out, float* nrm_out) {
+  if (!c) return PT_ERR_ARG;
+  if (c->tgt_type < 0) return fail(c, PT_ERR_STATE, "no resident targets");
+  if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k = %d out of range [1, %d]", k, PT_MAX_K);
+  if (c->m && !idx_out) return fail(c, PT_ERR_ARG, "idx output is null");
+  const bool blend = blend_mode >= 0 && (rgb_out || nrm_out);
+  if (blend && blend_mode != PT_BLEND_MEAN && blend_mode != PT_BLEND_INV_D2) return fail(c, PT_ERR_ARG, "unknown blend mode %d", blend_mode);
+  if (blend && !c->has_attr) return fail(c, PT_ERR_STATE, "no attribute table resident");
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t m = c->m;
+  RES(c, c->q_idx, std::max<uint64_t>(m, 1) * k * sizeof(uint32_t));
+  RES(c, c->q_d2, std::max<uint64_t>(m, 1) * k * sizeof(double));
+  if (blend) { RES(c, c->b_rgb, std::max<uint64_t>(m, 1) * 12); RES(c, c->b_nrm, std::max<uint64_t>(m, 1) * 12); }
+  const BlendReq br{blend_mode, (float*)c->b_rgb.p, (float*)c->b_nrm.p};
+  { int r = run_query(c, c->t_xyz.p, c->tgt_type, m, k, nullptr, (uint32_t*)c->q_idx.p, (double*)c->q_d2.p, blend ? &br : nullptr); if (r != PT_OK) return r; }
+  if (m) {
+    HIPCHK(c, hipMemcpyAsync(idx_out, c->q_idx.p, m * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (d2_out) HIPCHK(c, hipMemcpyAsync(d2_out, c->q_d2.p, m * k * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (blend && rgb_out) HIPCHK(c, hipMemcpyAsync(rgb_out, c->b_rgb.p, m * 12, hipMemcpyDeviceToHost, c->stream));
+    if (blend && nrm_out) HIPCHK(c, hipMemcpyAsync(nrm_out, c->b_nrm.p, m * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return PT_OK;
 }
 
 int pt_resident_target_ids(pt_ctx* c, uint32_t* ids_dev) {

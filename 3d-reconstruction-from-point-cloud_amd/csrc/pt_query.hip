@@ -1516,7 +1516,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
     const int sx = (u[0] - (double)cc[0]) >= 0.5 ? 0 : -1, sy = (u[1] - (double)cc[1]) >= 0.5 ? 0 : -1, sz = (u[2] - (double)cc[2]) >= 0.5 ? 0 : -1;
     double bnd = INFINITY;
     if constexpr (BND) {
-      static_assert(!DBL && !BLEND, "the bounded variant is built for fp32 clouds without the fused blend");
+      static_assert(!BLEND, "the bounded variant is built without the fused blend");
       if (active) bnd = tb.bound[tr.id];
     }
     const bool scan1 = active && !(BND && bnd < 0.0);      // (a negative bound -- "nothing from this cloud" -- skips pass 1 too; pass 2 prunes itself)
@@ -1570,10 +1570,13 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
     if constexpr (DBL) {
       // Rounded coordinates move every difference by at most E per axis (source + target rounding), i.e. every distance
       // by at most sqrt(3) E: k candidates lie within sqrt(kv') + sqrt(3) E of the target, so the true top k do, and
-      // their rounded distances are within another sqrt(3) E.  (1.0000005 covers sqrtf's rounding.)
-      const float e_t = 5.9604645e-8f * fmaxf(fmaxf(fabsf(tr.x), fabsf(tr.y)), fabsf(tr.z));
-      const float r = sqrtf(thr) * 1.0000005f + 3.4642f * (dd.e_src + e_t) * 1.000001f;
-      thr = r * r * 1.0000039f + 1e-30f;
+      // their rounded distances are within another sqrt(3) E.  (1.0000005 covers sqrtf's rounding.)  A caller's bound (BND) is on
+      // EXACT distances: what it lets through has a rounded distance within ONE sqrt(3) E of it, so the same widening covers it.
+      if (!BND || thr >= 0.f) {
+        const float e_t = 5.9604645e-8f * fmaxf(fmaxf(fabsf(tr.x), fabsf(tr.y)), fabsf(tr.z));
+        const float r = sqrtf(thr) * 1.0000005f + 3.4642f * (dd.e_src + e_t) * 1.000001f;
+        thr = r * r * 1.0000039f + 1e-30f;
+      }
     }
 #if defined(PT_ABLATE) && PT_ABLATE == 2
     if (thr >= 0.f) continue;                       // timing-only build: staging + pass 1 (results are garbage)
@@ -2022,11 +2025,19 @@ void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* c
   if (!nb) return;
   const TileBlend bl{attr, n_attr, mode, rgb_out, nrm_out};
   const TileBlocks tbk{blocks, retry, retry_n, (uint32_t)PT_TILE_CAP_LARGE, bound};
-  if (bound) {                                       // bounded variant: fp32 clouds, no fused blend, k <= 24 (pt_api.hip only sends those here)
-#define PT_TILE_LAUNCHB(KK, CAP, TH, KCH)                                                                                                                 \
-  hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH, false, false, false, KCH, true>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, \
-                     out_idx, out_d2, todo, todo_n, bl, tbk, TileDouble{nullptr, nullptr, 0.f})
-    if (geometry == 1 && k <= 16) {
+  if (bound) {                                       // bounded variant: no fused blend (pt_api.hip only sends those here); round 4: fp64 clouds and k in 25..32 too
+#define PT_TILE_LAUNCHB1(KK, CAP, TH, WD, DB, KCH)                                                                                                     \
+  hipLaunchKernelGGL((knn_tile_kernel<KK, CAP, TH, WD, false, DB, KCH, true>), dim3(nb), dim3(TH), 0, s, gp, src, cell_start, tgt, tblock_start, k, \
+                     out_idx, out_d2, todo, todo_n, bl, tbk, TileDouble{src_exact, tgt_exact, e_src})
+#define PT_TILE_LAUNCHB(KK, CAP, TH, KCH)                             \
+  do {                                                                \
+    if (src_exact) PT_TILE_LAUNCHB1(KK, CAP, TH, false, true, KCH);   \
+    else PT_TILE_LAUNCHB1(KK, CAP, TH, false, false, KCH);            \
+  } while (0)
+    if (k > 24) {
+      if (src_exact) PT_TILE_LAUNCHB1(32, PT_TILE_CAP_WIDE, 512, true, true, 32);
+      else PT_TILE_LAUNCHB1(32, PT_TILE_CAP_WIDE, 512, true, false, 32);
+    } else if (geometry == 1 && k <= 16) {
       if (k <= 8) PT_TILE_LAUNCHB(8, PT_TILE_CAP_SMALL_8, 512, 8);
       else PT_TILE_LAUNCHB(16, PT_TILE_CAP_SMALL_16, 512, 16);
     } else {
@@ -2036,6 +2047,7 @@ void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* c
       else PT_TILE_LAUNCHB(32, PT_TILE_CAP_LARGE, 768, 24);
     }
 #undef PT_TILE_LAUNCHB
+#undef PT_TILE_LAUNCHB1
     return;
   }
   const TileDouble dd{src_exact, tgt_exact, e_src};

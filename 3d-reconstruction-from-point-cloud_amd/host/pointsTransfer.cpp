@@ -110,6 +110,11 @@ int main(int argc, char** argv) {
   int gpus = 0, rank = -1;
   bool finalize = false;
   std::string rendezvous;
+  // --synthetic N M SEED [--clustered] [--xyz f32|f16|f64]: SURVEY.md Appendix C's generator instead of the two files (the positional
+  // arguments are ignored): the BASELINE configurations run through this binary without a cloud on disk -- no mesh, so no texture
+  bool synthetic = false;
+  uint64_t syn_n = 0, syn_m = 0, syn_seed = 0;
+  int syn_dist = PT_DIST_UNIFORM, syn_type = PT_F32;
   std::vector<std::string> passthrough;            // the options a launcher hands to its rank / finalize processes
   for (int i = 3; i < argc; ++i) {
     const std::string a = argv[i];
@@ -129,6 +134,10 @@ int main(int argc, char** argv) {
     else if (a == "--finalize") { finalize = true; continue; }
     else if (a == "--ply-threads") ply_threads = std::max(0, std::atoi(val()));
     else if (a == "--blend") mode = std::string(val()) == "invd2" ? PT_BLEND_INV_D2 : PT_BLEND_MEAN;
+    else if (a == "--synthetic") { syn_n = std::strtoull(val(), nullptr, 0); syn_m = std::strtoull(val(), nullptr, 0); syn_seed = std::strtoull(val(), nullptr, 0); synthetic = true; }
+    else if (a == "--clustered") syn_dist = PT_DIST_CLUSTERED;
+    else if (a == "--xyz") { const std::string t = val(); syn_type = t == "f16" ? PT_F16 : (t == "f64" ? PT_F64 : PT_F32); }
+    else if (a == "--rendezvous-root") { rendezvous = val(); continue; }      // (the launcher's: where its rendezvous directory is made)
     else { std::cerr << "unknown option " << a << std::endl; return 2; }
     for (int j = i_before; j <= i; ++j) passthrough.push_back(argv[j]);
   }
@@ -157,6 +166,62 @@ int main(int argc, char** argv) {
 
   const auto t_total = clk::now();
   auto t_task = clk::now();
+
+  if (synthetic) {
+    // generated cloud and targets, the reference's report lines in the reference's order (:178 ... :623); `--neighbors FILE` keeps the
+    // index matrix, `--out FILE` the blended attributes as an ASCII table (there is no mesh to write them onto)
+    pt_ctx* sc = nullptr;
+    int src = pt_ctx_create(&sc, &device, 1);
+    if (src != PT_OK) { std::cerr << "pointsTransfer: no usable HIP device (pt_ctx_create returned " << src << "); there is no CPU fallback" << std::endl; return 1; }
+    auto sdie = [&](const char* what) { std::cerr << "pointsTransfer: " << what << ": " << pt_last_error(sc) << std::endl; pt_ctx_destroy(sc); return 1; };
+    pt_set_param(sc, "k_hint", (double)K);
+    pt_set_param(sc, "sync", 1.0);
+    if (pt_build_synth(sc, syn_n, syn_seed, syn_dist, syn_type, -1, 0.0, 0.0) != PT_OK) return sdie("build failed");
+    pt_stats_t st0;
+    pt_stats(sc, &st0);
+    std::cout << "PC Point count: " << syn_n << std::endl;
+    std::cout << "Read point set in: " << std::max(0.0, since(t_task) - st0.ms_build * 1e-3) << " seconds" << std::endl;      // (generation; the build is the next line)
+    std::cout << "Built Kd tree in: " << st0.ms_build * 1e-3 << " seconds" << std::endl;
+    t_task = clk::now();
+    if (pt_targets_synth(sc, syn_m, syn_seed, syn_dist, syn_type == PT_F64 ? PT_F64 : (syn_type == PT_F16 ? PT_F16 : PT_F32), -1, 0.0, 0.0) != PT_OK) return sdie("target generation failed");
+    const uint64_t M = pt_num_targets(sc);
+    std::cout << "Mesh vertex count: " << M << std::endl;
+    std::cout << "Mesh face count: 0" << std::endl;
+    std::cout << "Read mesh faces: " << since(t_task) << " seconds" << std::endl;
+    t_task = clk::now();
+    std::vector<uint32_t> idx(M * (size_t)K);
+    std::vector<double> d2(M * (size_t)K);
+    std::vector<float> rgb(M * 3), nrm(M * 3);
+    if (pt_query_resident_host(sc, K, mode, idx.data(), d2.data(), rgb.data(), nrm.data()) != PT_OK) return sdie("query failed");
+    pt_stats_t st;
+    pt_stats(sc, &st);
+    std::cout << "Neighbor search total time: " << since(t_task) << " seconds" << std::endl;
+    std::cout << "Draw triangles total time: 0 seconds" << std::endl;             // (the blend ran inside the search: pt_stats.ms_query)
+    t_task = clk::now();
+    if (!nbr_name.empty()) {
+      std::ofstream o(nbr_name, std::ios::binary);
+      o.write(reinterpret_cast<const char*>(idx.data()), (std::streamsize)(idx.size() * sizeof(uint32_t)));
+    }
+    if (!json_name.empty()) {
+      std::ofstream j(json_name);
+      j.precision(9);
+      j << "{\"synthetic\": {\"n\": " << syn_n << ", \"m\": " << M << ", \"seed\": " << syn_seed << ", \"clustered\": " << (syn_dist == PT_DIST_CLUSTERED ? 1 : 0) << "}, \"k\": " << K
+        << ", \"pt_stats\": {\"ms_build\": " << st.ms_build << ", \"ms_sort_targets\": " << st.ms_sort_targets << ", \"ms_query\": " << st.ms_query << ", \"grid_dim\": [" << st.grid_dim[0] << ", "
+        << st.grid_dim[1] << ", " << st.grid_dim[2] << "], \"n_levels\": " << st.n_levels << ", \"pass1_pooled\": " << st.pass1_pooled << ", \"pass2_pooled\": " << st.pass2_pooled
+        << ", \"uniform_probe\": " << st.uniform_probe << ", \"n_leftover\": " << st.n_leftover << ", \"n_wave\": " << st.n_wave << ", \"device_bytes\": " << st.device_bytes
+        << ", \"targets_per_second_device\": " << (st.ms_build + st.ms_sort_targets + st.ms_query > 0 ? (double)M / ((st.ms_build + st.ms_sort_targets + st.ms_query) * 1e-3) : 0.0) << "}}\n";
+    }
+    std::cout << "Output time: " << since(t_task) << " seconds" << std::endl;
+    std::cout << "Total real time: " << since(t_total) << " seconds" << std::endl;
+    std::cerr << "[pt_hip] synthetic: grid " << st.grid_dim[0] << "x" << st.grid_dim[1] << "x" << st.grid_dim[2] << " cells, build " << st.ms_build << " ms, target sort " << st.ms_sort_targets
+              << " ms, kNN + blend " << st.ms_query << " ms (device time)" << std::endl;
+    pt_ctx_destroy(sc);
+    long virt, res;
+    mem_mib(virt, res);
+    std::cout << "VIRT: " << virt << " MiB" << std::endl;
+    std::cout << "RES:  " << res << " MiB" << std::endl;
+    return 0;
+  }
 
   // The context comes first: the cloud is parsed straight into page-locked planar arrays (x, y, z, colour bytes, normals:
   // 39 bytes per point instead of the 80-byte record) and every finished range of records is handed to the GPU while the

@@ -22,6 +22,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/statvfs.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -58,6 +59,13 @@ using clk = std::chrono::steady_clock;
 inline double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
 
 struct RefPoint { uint32_t id; double x, y, z; uint8_t rgb[3]; };
+
+// free bytes of the file system holding `dir` (0 when it cannot be told)
+inline uint64_t free_bytes(const std::string& dir) {
+  struct statvfs vs;
+  if (statvfs(dir.c_str(), &vs) != 0) return 0;
+  return (uint64_t)vs.f_bavail * (uint64_t)vs.f_frsize;
+}
 
 inline bool write_all(const std::string& path, const std::vector<std::pair<const void*, size_t>>& parts) {
   const std::string tmp = path + ".part";
@@ -184,7 +192,7 @@ inline int run_rank(const Options& o) {
   }
   pt_set_param(ctx, "k_hint", (double)o.K);
   // ---- cloud: this rank parses 1/world of the file and publishes the piece; the slab is then picked from all pieces --------------
-  const double wait_s = 3600.0;                  // (peers parse as long as this rank does; a peer that DIES ends the job through the launcher)
+  const double wait_s = 900.0;                   // (peers parse as long as this rank does -- a 1e9-point text cloud takes ~12 s per DESIGN 9; a peer that DIES ends the job through the launcher, this bound is for a launcher that was itself killed)
   long declared = 0;
   uint64_t my_first = 0, n_file = 0;
   {
@@ -217,7 +225,11 @@ inline int run_rank(const Options& o) {
     std::cerr << "[pt_hip rank " << rank << "] parsed records [" << my_first << ", " << my_first + part.n << ") of " << n_file << " (1/" << world << " of the file) in "
               << since(t_task) << " s" << std::endl;
     free_mem();
-    if (!wrote) return die("cannot write this rank's piece of the cloud into the rendezvous directory");
+    if (!wrote) {
+      std::cerr << "pointsTransfer[rank " << rank << "]: writing " << ((16 + (uint64_t)part.n * 39) >> 20) << " MiB into " << o.rendezvous << " failed (" << std::strerror(errno) << "; "
+                << (free_bytes(o.rendezvous) >> 20) << " MiB free there)" << std::endl;
+      return die("cannot write this rank's piece of the cloud into the rendezvous directory");
+    }
   }
   Pieces cloud;
   if (!cloud.open(o.rendezvous, world, wait_s) || cloud.n != n_file) return die("the pieces of the cloud in the rendezvous directory are incomplete");
@@ -403,10 +415,26 @@ inline int spawn_and_wait(const std::vector<std::vector<std::string>>& cmds, dou
 }
 
 inline int run_launcher(const Options& o, const std::string& self, const std::vector<std::string>& passthrough) {
-  char tmpl[] = "/tmp/pointsTransfer.XXXXXX";
-  if (!mkdtemp(tmpl)) { std::cerr << "pointsTransfer: cannot create a rendezvous directory" << std::endl; return 1; }
+  // The rendezvous directory receives the parsed cloud (39 bytes per point: 39 GB at 1e9 points) -- under $TMPDIR when that is set
+  // (a tmpfs /tmp holds it in RAM), else /tmp; `--rendezvous-root DIR` (o.rendezvous on the launcher) overrides both.
+  const char* env = std::getenv("TMPDIR");
+  const std::string root = !o.rendezvous.empty() ? o.rendezvous : std::string(env && *env ? env : "/tmp");
+  std::string tmpl = root + "/pointsTransfer.XXXXXX";
+  if (!mkdtemp(&tmpl[0])) { std::cerr << "pointsTransfer: cannot create a rendezvous directory under " << root << std::endl; return 1; }
   const std::string dir = tmpl;
   std::cerr << "[pt_hip launcher] rendezvous " << dir << std::endl;
+  {   // room for the pieces?  The cloud file's size bounds the point count from above (a binary record is >= 27 bytes, a text record >= 18)
+    struct stat st;
+    if (stat(o.cloud.c_str(), &st) == 0) {
+      const uint64_t need = (uint64_t)st.st_size / 18u * 39u / 2u, have = free_bytes(dir);      // (half the worst case: text records are ~60 bytes)
+      if (have && need > have) {
+        std::cerr << "pointsTransfer: the rendezvous directory " << dir << " has " << (have >> 20) << " MiB free, the parsed cloud may need " << (need >> 20)
+                  << " MiB: set TMPDIR or --rendezvous-root to a larger file system" << std::endl;
+        rmdir(dir.c_str());
+        return 1;
+      }
+    }
+  }
   auto cmd_for = [&](const std::vector<std::string>& extra) {
     std::vector<std::string> c = {self, o.cloud, o.mesh};
     c.insert(c.end(), passthrough.begin(), passthrough.end());

@@ -196,6 +196,9 @@ int  pt_query_resident(pt_ctx*, int k, uint32_t* idx_dev, double* d2_dev_or_null
 int  pt_query_blend_resident(pt_ctx*, int k, int blend_mode, uint32_t* idx_dev, double* d2_dev_or_null,
                              float* rgb_out_dev, float* nrm_out_dev);
 /* Global index (position in the whole target set) of each resident target, device u32[m]. */
+/* The same for a C++ host that holds no device memory (the CLI's --synthetic): idx / d2 / rgb / nrm come back to HOST memory
+ * ([m][k], [m][k], [m][3], [m][3], m = pt_num_targets; d2 / rgb / nrm may be NULL, blend_mode < 0 skips the blend). */
+int  pt_query_resident_host(pt_ctx*, int k, int blend_mode, uint32_t* idx_out, double* d2_out_or_null, float* rgb_out_or_null, float* nrm_out_or_null);
 int  pt_resident_target_ids(pt_ctx*, uint32_t* ids_dev);
 /* Planar xyz (f32 or f64 as generated) of the resident targets, copied to a device buffer. */
 int  pt_resident_target_xyz(pt_ctx*, void* xyz_dev);

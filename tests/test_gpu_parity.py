@@ -1186,6 +1186,31 @@ def _write_ascii_plys(pc, mesh, src, rgb, verts, uv, vrgb, faces):
             f.write("3 %d %d %d\n" % tuple(fc))
 
 
+def test_cli_synthetic_runs_the_baseline_configs_without_files(tmp_path, pkg, oracle):
+    """`pointsTransfer - - --synthetic N M SEED`: the generator of Appendix C instead of the two files, the reference's report
+    lines in the reference's order, `--neighbors` the index matrix -- config 1 (10k / 1k / k = 1, seed 0xC1) against the oracle's brute force."""
+    exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "pointsTransfer")
+    n, m, k, seed = 10_000, 1_000, 1, 0xC1
+    nb = tmp_path / "nbr.bin"; js = tmp_path / "s.json"
+    r = subprocess.run([exe, "-", "-", "--synthetic", str(n), str(m), hex(seed), "--k", str(k), "--neighbors", str(nb), "--json", str(js)], capture_output=True, text=True,
+                       cwd=tmp_path, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    heads = ["PC Point count: %d" % n, "Read point set in:", "Built Kd tree in:", "Mesh vertex count: %d" % m, "Mesh face count: 0", "Read mesh faces:",
+             "Neighbor search total time:", "Draw triangles total time:", "Output time:", "Total real time:", "VIRT:", "RES:  "]
+    assert len(lines) == len(heads) and all(l.startswith(h) for l, h in zip(lines, heads)), r.stdout
+    got = np.fromfile(nb, np.uint32).reshape(m, k)
+    wi, _ = oracle.knn_bruteforce(oracle.synth_xyz(seed, 0, n), oracle.synth_xyz(seed, 1, m), k)
+    assert np.array_equal(got, wi)
+    import json as _json
+    assert _json.load(open(js))["synthetic"]["n"] == n
+    # config 2's shape (10M / 1M / k = 8) through the same binary: properties only (sorted distances are not written; every index valid)
+    r = subprocess.run([exe, "-", "-", "--synthetic", "10000000", "1000000", "0xC2", "--k", "8", "--neighbors", str(nb)], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(nb, np.uint32).reshape(1_000_000, 8)
+    assert got.max() < 10_000_000 and (np.sort(got, axis=1)[:, 1:] != np.sort(got, axis=1)[:, :-1]).all()
+
+
 @pytest.mark.parametrize("fmt", ["ascii", "binary"])
 def test_cli_writes_the_texture(tmp_path, pkg, oracle, fmt):
     """pointsTransfer cloud.ply mesh.ply -> texture.png (reference src/pointsTransfer.cpp:613-615): search (K = 20), per-face bake,
@@ -1408,8 +1433,12 @@ def test_native_exchange_two_ranks_over_rccl(pkg, oracle, tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs: this box shows %d (RCCL cannot place two ranks on one device)" % torch.cuda.device_count())
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_worker.py")
+    import socket
+    with socket.socket() as so:                              # a free rendezvous port on the loop-back interface (as bench.py's launcher picks one)
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", worker, str(tmp_path)], capture_output=True, text=True, timeout=600)
+                        "--master-port", str(port), worker, str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
 

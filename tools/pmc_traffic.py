@@ -1,6 +1,8 @@
 """Derive profiles/*_pmc_traffic.json from two rocprofv3 counter_collection CSVs (FETCH_SIZE pass, WRITE_SIZE pass).
 
-Per kernel the LARGEST dispatch is kept (the full-size launch); HBM bytes = FETCH_SIZE[KB]*1024*2 + WRITE_SIZE[KB]*1024
+Per kernel the largest dispatch OF THE LAST STEP is kept (the full-size launch of the timed path: round 3 took the largest of the whole
+run, which for kernels the first build runs differently -- scatter_pool_kernel with block ids -- was not the step's; the run-wide
+maximum stays beside it as `largest_in_run_hbm_bytes`); HBM bytes = FETCH_SIZE[KB]*1024*2 + WRITE_SIZE[KB]*1024
 (MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads).
 usage: pmc_traffic.py fetch.csv write.csv "<workload note>" > out.json
 """
@@ -30,11 +32,26 @@ def last_step(path, counter):
     ids = sorted(d)
     starts = [i for i, k in enumerate(ids) if d[k][0] in ("bbox_kernel", "bbox_sample_kernel")]
     return sum(d[k][1] for k in ids[starts[-1]:]) if starts else None
-f = largest(sys.argv[1], "FETCH_SIZE"); w = largest(sys.argv[2], "WRITE_SIZE")
+def largest_in_last_step(path, counter):
+    d = per_dispatch(path, counter)
+    ids = sorted(d)
+    starts = [i for i, k in enumerate(ids) if d[k][0] in ("bbox_kernel", "bbox_sample_kernel")]
+    best = {}
+    for k in (ids[starts[-1]:] if starts else ids):
+        name, v = d[k]
+        if v >= best.get(name, -1.0):
+            best[name] = v
+    return best
+fa, wa = largest(sys.argv[1], "FETCH_SIZE"), largest(sys.argv[2], "WRITE_SIZE")
+f = largest_in_last_step(sys.argv[1], "FETCH_SIZE"); w = largest_in_last_step(sys.argv[2], "WRITE_SIZE")
+for k in fa:                       # kernels that only run outside the step (generators, the first build's own) keep their run-wide figure
+    if k not in f:
+        f[k] = fa[k]; w.setdefault(k, wa.get(k, 0.0))
 out = {"workload": sys.argv[3] if len(sys.argv) > 3 else "", "kernels": {}}
 for k in f:
     rd = f[k] * 1024 * 2; wr = w.get(k, 0.0) * 1024
-    out["kernels"][k] = {"FETCH_SIZE_KB": f[k], "WRITE_SIZE_KB": w.get(k, 0.0), "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr}
+    out["kernels"][k] = {"FETCH_SIZE_KB": f[k], "WRITE_SIZE_KB": w.get(k, 0.0), "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr,
+                         "largest_in_run_hbm_bytes": fa.get(k, 0.0) * 2048 + wa.get(k, 0.0) * 1024}
 sf, sw = last_step(sys.argv[1], "FETCH_SIZE"), last_step(sys.argv[2], "WRITE_SIZE")
 if sf is not None and sw is not None:
     out["step"] = {"note": "all dispatches of the last step (rebuild .. blend)", "FETCH_SIZE_KB": sf, "WRITE_SIZE_KB": sw,

@@ -90,6 +90,8 @@ elif what in ("clus", "c5"):
                 p.set_param("refine_cells_per_point", float(w[w.index("cpp") + 1]))
             if "macros" in w:
                 p.set_param("refine_macros", float(w[w.index("macros") + 1]))
+            if "tile" in w:
+                p.set_param("tile", float(w[w.index("tile") + 1]))
             if "thr" in w:
                 p.set_param("refine_threshold", float(w[w.index("thr") + 1]))
             if "rho" in w:
