@@ -46,6 +46,9 @@ struct pt_ctx {
   int sync = 1;
   int adaptive = 1;            // refine the cell size when the occupied cells hold far more than rho points (non-uniform clouds)
   int tile = 1;                // 1: tile kernel + group kernel for leftovers (fp32, unbounded); 0: group kernel only
+  int dup_runs = 1;            // leaves of refined cells that hold one position many times keep their PT_DUP_KEEP lowest indices in front ("dup_runs", 0: off -- a measurement switch)
+  int tile_sparse = 2;         // the tile kernel over a LIST of the blocks that hold targets: 0 never, 1 always, 2 on clouds that leave most of their grid empty
+  int tile_contrast = 0;       // clouds with strong density contrast: 0 every target gets a wave (round 2), 1 the tile kernel first (k <= 24), what it cannot settle gets a wave
   size_t dev_bytes = 0;
 
   // source cloud (slab-local when built from a slab)
@@ -116,7 +119,7 @@ struct pt_ctx {
   DevBuf ttb_mem;
 
   // scratch
-  DevBuf bbox6, counter, q_idx, q_d2, b_rgb, b_nrm, aos_stage, misc, bounds, todo, retry, heavy;
+  DevBuf bbox6, counter, q_idx, q_d2, b_rgb, b_nrm, aos_stage, misc, bounds, todo, retry, heavy, tlist;
   uint64_t* h_bbox = nullptr;   // pinned
   uint32_t* h_counter = nullptr;
 
@@ -500,6 +503,18 @@ int rebuild(pt_ctx* c) {
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));                         // (n1 above is host memory the last copy reads)
     c->n_nodes = n1;
+    // runs of identical points inside the nodes' leaves (pt_refine.hip, dedup_leaves_kernel): the PT_DUP_KEEP lowest indices to the front
+    c->st.dup_leaves = 0;
+    if (n1 && c->dup_runs) {
+      static_assert(PT_MAX_K <= PT_DUP_KEEP, "a leaf's front must hold every point a query may return from it");
+      uint32_t* dst = (uint32_t*)c->counter.p + 2;
+      HIPCHK(c, hipMemsetAsync(dst, 0, 8, c->stream));
+      if (c->src_type == PT_F32) pt_launch_dedup_leaves<RecF>((RecF*)c->rec.p, (RecF*)c->rec_tmp.p, 0, n1, (uint32_t*)c->nodes.p, dst, c->stream);
+      else pt_launch_dedup_leaves<RecD>((RecD*)c->rec.p, (RecD*)c->rec_tmp.p, 0, n1, (uint32_t*)c->nodes.p, dst, c->stream);
+      HIPCHK(c, hipMemcpyAsync(c->h_counter + 2, dst, 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      c->st.dup_leaves = (int32_t)std::min<uint32_t>(c->h_counter[2], 0x7FFFFFFFu);
+    }
     if (c->src_type == PT_F64 && c->stb.shadow32 && n1) pt_launch_reshadow((const RecD*)c->rec.p, (uint32_t)c->n, c->stb.shadow32, c->stream);
     HIPCHK(c, hipGetLastError());
   }
@@ -592,7 +607,7 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
   // (round 4: fp64 clouds and k in 25..32 as well -- ADVICE r3: since every chunk of a streamed cloud brings bounds, those went to the
   //  8-lane group kernel in EVERY chunk, the first, unbounded one included)
   const bool tile_bounded = bound2_dev && c->tile_bounds && !br && k <= PT_TILE_MAX_K;
-  const bool use_tile = c->tile && !contrast && (!bound2_dev || tile_bounded) && m && k <= PT_TILE_MAX_K && h2_ok && (ttype == PT_F32 || c->rec32_valid);
+  const bool use_tile = c->tile && (!contrast || (c->tile_contrast && k <= 24)) && (!bound2_dev || tile_bounded) && m && k <= PT_TILE_MAX_K && h2_ok && (ttype == PT_F32 || c->rec32_valid);
   // The tile kernel over all blocks (+ the large geometry for the blocks the small one had to pass on); what it cannot
   // settle is on the todo list afterwards.  fp64 clouds: the LDS image is the fp32 shadow of the sorted records, the exact
   // 32-byte records are fetched for the few candidates that reach the ranking pass.
@@ -602,17 +617,35 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
   auto tile_launches = [&](const RecF* src32, const RecF* tgt32, const RecD* src64, const RecD* tgt64, uint32_t* todo_n) -> int {
     const double cells = (double)c->gp.dim[0] * c->gp.dim[1] * c->gp.dim[2];
     // regions (10^3 cells) that fit the small capacity with headroom run the two-workgroups-per-CU geometry
-    const int tile_small = c->tile == 2 || (c->tile == 1 && (double)c->n / cells * 1000.0 * 1.05 <= (double)(k <= 8 ? PT_TILE_CAP_SMALL_8 : PT_TILE_CAP_SMALL_16));
+    const bool empty_grid = c->adaptive && (c->st.n_refine > 0 || c->st.rho_occupied > 1.25 * c->rho / (1.0 - std::exp(-c->rho)));      // surfaces, clusters: most cells are empty
+    const bool fits_small = (double)c->n / cells * 1000.0 * 1.05 <= (double)(k <= 8 ? PT_TILE_CAP_SMALL_8 : PT_TILE_CAP_SMALL_16);
+    // geometry: 1 = two 512-thread workgroups per CU (k <= 16), 4 = two 384-thread ones (k in 17..24), 0 = one large one.  A cloud that leaves most
+    // of its grid empty tries the two-per-CU geometry first whatever the average density says: its blocks that are over budget get the large one
+    const int tile_small = k <= 16 ? (c->tile == 2 || (c->tile == 1 && (fits_small || empty_grid)) ? 1 : 0)
+                                   : (k <= 24 ? (c->tile == 2 || (c->tile == 1 && (fits_small || empty_grid)) ? 4 : 0) : 0);
     HIPCHK(c, hipMemsetAsync(todo_n, 0, 4, c->stream));
     const Attr* battr = br ? (const Attr*)c->attr.p : nullptr;
-    const bool second_chance = tile_small && k <= 16;         // small geometry: over-budget blocks get the large one
+    const bool second_chance = tile_small != 0;               // two-per-CU geometries: over-budget blocks get the large one
+    // clouds that leave most of their grid empty (surfaces, clusters: the occupied cells hold far more than rho points, or the cell size
+    // was refined): one workgroup per block that HOLDS TARGETS instead of one per block of the grid -- one read-back for the list's length
+    const uint32_t* blist = nullptr;
+    uint32_t nlist = 0;
+    if (c->tile_sparse == 1 || (c->tile_sparse == 2 && empty_grid)) {
+      RES(c, c->tlist, (size_t)c->gp.nblocks * sizeof(uint32_t));
+      uint32_t* lcnt = (uint32_t*)c->counter.p + 7;
+      pt_launch_tblock_list(c->ttb.block_start, (uint32_t)c->gp.nblocks, (uint32_t*)c->tlist.p, lcnt, c->stream);
+      HIPCHK(c, hipMemcpyAsync(c->h_counter + 7, lcnt, 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      blist = (const uint32_t*)c->tlist.p; nlist = c->h_counter[7];
+      if (!nlist) return PT_OK;
+    }
     uint32_t* retry_n = (uint32_t*)c->counter.p + 5;
     if (second_chance) {
       HIPCHK(c, hipMemsetAsync(retry_n, 0, 4, c->stream));
       RES(c, c->retry, (size_t)c->gp.nblocks * sizeof(uint32_t));
     }
     pt_launch_knn_tile(c->gp, src32, (const uint32_t*)c->cell_start.p, tgt32, c->ttb.block_start, k, idx_dev, d2_dev, (uint32_t*)c->todo.p, todo_n,
-                       tile_small, battr, (uint32_t)c->n_total, br ? br->mode : 0, br ? br->rgb_out : nullptr, br ? br->nrm_out : nullptr, nullptr, 0,
+                       tile_small, battr, (uint32_t)c->n_total, br ? br->mode : 0, br ? br->rgb_out : nullptr, br ? br->nrm_out : nullptr, blist, nlist,
                        second_chance ? (uint32_t*)c->retry.p : nullptr, retry_n, src64, tgt64, c->e_src, c->stream, bound2_dev);
     if (second_chance) {
       retry_launch = [=]() {
@@ -884,7 +917,7 @@ void pt_ctx_destroy(pt_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in_xyz, &c->in_gidx, &c->attr, &c->rec, &c->rec_tmp, &c->cell_start, &c->stb_mem, &c->t_xyz, &c->t_gidx, &c->trec,
                    &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr, &c->retry, &c->rec32, &c->up_rgb, &c->up_nrm, &c->x_bounds, &c->x_counts, &c->x_matrix, &c->x_off, &c->x_req, &c->x_row, &c->x_rreq,
-                   &c->x_rxyz, &c->x_rbound, &c->x_ans_i, &c->x_ans_d, &c->x_back_i, &c->x_back_d, &c->x_flags, &c->x_rows, &c->cell_node, &c->nodes, &c->heavy, &c->near_node, &c->xyz32};
+                   &c->x_rxyz, &c->x_rbound, &c->x_ans_i, &c->x_ans_d, &c->x_back_i, &c->x_back_d, &c->x_flags, &c->x_rows, &c->cell_node, &c->nodes, &c->heavy, &c->near_node, &c->xyz32, &c->tlist};
   for (DevBuf* b : all) release(c, *b);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);
@@ -921,6 +954,9 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!strcmp(name, "sync")) { c->sync = value != 0; return PT_OK; }
   if (!strcmp(name, "adaptive")) { c->adaptive = value != 0; return PT_OK; }
   if (!strcmp(name, "tile")) { c->tile = (int)value; return PT_OK; }
+  if (!strcmp(name, "tile_sparse")) { c->tile_sparse = (int)value; return PT_OK; }
+  if (!strcmp(name, "dup_runs")) { c->dup_runs = value != 0; return PT_OK; }
+  if (!strcmp(name, "tile_contrast")) { c->tile_contrast = (int)value; return PT_OK; }
   if (!strcmp(name, "grid_hint")) { c->grid_hint = value != 0; if (!c->grid_hint) c->hint_h = 0.0; return PT_OK; }
   if (!strcmp(name, "refine_cells_per_point")) { if (!(value > 0 && value <= 1e6)) return fail(c, PT_ERR_ARG, "refine_cells_per_point out of range"); c->refine_cpp = value; return PT_OK; }
   if (!strcmp(name, "refine_macros")) { if (!(value >= 1 && value <= PT_MAX_MACROS)) return fail(c, PT_ERR_ARG, "refine_macros out of range"); c->refine_macros = (int)value; return PT_OK; }

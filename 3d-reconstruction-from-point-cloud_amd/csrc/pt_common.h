@@ -31,6 +31,13 @@
 #define PT_NODE_CHILD (PT_NODE_START + 513)
 #define PT_NODE_WORDS 1040
 #define PT_REFINE_DEPTH 3           // levels below the grid: sub-cells of 1/8, 1/64, 1/512 of a cell side
+// Runs of IDENTICAL points (round 4): a leaf sub-cell of a node whose points all share one position -- what a quantised cloud (fp16
+// coordinates, scanner lattices) leaves in its dense places: clumps of up to 10^5 duplicates -- keeps its PT_DUP_KEEP lowest original
+// indices, sorted, at the front of its range, and the leaf's child link says so: PT_LEAF_TRUNC | length of that front.  Under the
+// total order (d2, index) no other point of the leaf can be among the k <= PT_DUP_KEEP nearest of any target, so a search that reads
+// the front only is exact; the leaf's range still holds every one of its points (a flat scan of the cell stays valid).
+#define PT_DUP_KEEP 32
+#define PT_LEAF_TRUNC 0x80000000u
 
 struct RecF { float x, y, z; uint32_t id; };                     // 16 B
 struct RecD { double x, y, z; uint32_t id; uint32_t pad; };      // 32 B

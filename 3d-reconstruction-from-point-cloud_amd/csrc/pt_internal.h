@@ -99,6 +99,8 @@ void pt_launch_mark_near(const GridParams& gp, const Rec* tgt, const uint32_t* l
 // quad-per-target LDS tile kernel (fp32 records, k <= 32); leftovers go to todo[*todo_n] and are finished by pt_launch_knn(list=todo)
 // staged-region capacities (records) of the tile kernel's geometries: what is left of 80 KB (two workgroups per CU) or
 // 160 KB (one) after the per-lane queue segments and the cell table
+// the blocks with at least one target (tblock_start: the target sort's block table), appended to list[*count] (count zeroed here)
+void pt_launch_tblock_list(const uint32_t* tblock_start, uint32_t nblocks, uint32_t* list, uint32_t* count, hipStream_t s);
 constexpr int PT_TILE_CAP_SMALL_8 = 4400, PT_TILE_CAP_SMALL_16 = 3888, PT_TILE_CAP_LARGE = 8448, PT_TILE_CAP_WIDE = 8960;
 constexpr int PT_TILE_MAX_K = 32;      // beyond this the group kernel answers everything
 void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* cell_start, const RecF* tgt, const uint32_t* tblock_start,
@@ -184,6 +186,10 @@ void pt_launch_heavy_subcells(uint32_t n0, uint32_t n1, uint32_t threshold, uint
 // counting sort of the records of the nodes [n0, n1) by sub-cell, in place (tmp: scratch of the same size as rec), + their start tables
 template <class Rec>
 void pt_launch_refine_nodes(const GridParams& gp, Rec* rec, Rec* tmp, uint32_t n0, uint32_t n1, uint32_t* nodes, hipStream_t s);
+// leaves of the nodes [n0, n1) that hold more than PT_DUP_KEEP copies of ONE position: the PT_DUP_KEEP lowest indices to the front, the
+// leaf's child link tagged (pt_common.h); tmp: scratch as large as rec; stats2 (device, may be null): += {leaves tagged, points behind a front}
+template <class Rec>
+void pt_launch_dedup_leaves(Rec* rec, Rec* tmp, uint32_t n0, uint32_t n1, uint32_t* nodes, uint32_t* stats2, hipStream_t s);
 void pt_launch_reshadow(const RecD* rec, uint32_t n, RecF* shadow, hipStream_t s);
 // k-NN over the refined grid (group kernel with hierarchical cell scans): same contract as pt_launch_knn
 template <class Rec>

@@ -264,7 +264,13 @@ struct HierScan {
         const uint32_t sub = (uint32_t)(r2 * 8 + x);
         uint32_t child = 0;
         bool cut = x > xb || (sweep && sub == own);
-        if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) { if (!cut) { child = (uint32_t)__shfl((int)chl, x, GL); cut = child != 0u; } }
+        if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) {
+          if (!cut) {
+            child = (uint32_t)__shfl((int)chl, x, GL);
+            if (child & PT_LEAF_TRUNC) child = 0u;          // a leaf of identical points with its lowest indices in front (pt_common.h): scanned whole here, which is exact too
+            cut = child != 0u;
+          }
+        }
         if (!cut) {
           if (run_e == run_s) run_s = (uint32_t)__shfl((int)stl, x, GL);
           run_e = x < 7 ? (uint32_t)__shfl((int)stl, x + 1, GL) : end8;
@@ -965,13 +971,18 @@ struct WaveScan {
       first = false;
       uint32_t stl = 0, chl = 0;                            // lane x: start of sub-cell x of the row (x = 8: its end) and its child
       if (lane < 9) stl = N[PT_NODE_START + r2 * 8 + lane];
-      if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) { if (lane < 8) chl = N[PT_NODE_CHILD + r2 * 8 + lane]; }
+      if (lane < 8) chl = N[PT_NODE_CHILD + r2 * 8 + lane];  // (the last level has no children, but its leaves may carry the identical-points tag)
       // leaf sub-cells next to each other are one contiguous run of records, scanned in one go; a sub-cell that is a node, the own
       // sub-cell (already done) and the end of the row cut the run.  The row's leaves first, then its children one by one.
       uint32_t kids = 0, run_s = 0, run_e = 0;
       for (int x = xa; x <= xb + 1; ++x) {
         bool cut = x > xb || (sweep && (uint32_t)(r2 * 8 + x) == own);
-        if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) { if (!cut && readlane_u32(chl, x) != 0u) { kids |= 1u << x; cut = true; } }
+        uint32_t front = 0;                                   // > 0: a leaf of identical points, this many of them (the lowest indices) are all a search needs
+        if (!cut) {
+          const uint32_t ch = readlane_u32(chl, x);
+          if (ch & PT_LEAF_TRUNC) { front = ch & ~PT_LEAF_TRUNC; cut = true; }
+          else if (ch != 0u) { kids |= 1u << x; cut = true; }
+        }
         if (!cut) {
           if (run_e == run_s) run_s = readlane_u32(stl, x);
           run_e = readlane_u32(stl, x + 1);
@@ -979,6 +990,7 @@ struct WaveScan {
         }
         if (run_e > run_s) range(run_s, run_e);
         run_s = run_e = 0;
+        if (front) { const uint32_t fs = readlane_u32(stl, x); range(fs, fs + front); }
       }
       if constexpr (DEPTH + 1 < PT_REFINE_DEPTH) {
         while (kids) {
@@ -1295,7 +1307,7 @@ struct TileDouble { const RecD* src; const RecD* tgt; float e_src; };
 // entries leaves l32[KC..K) at +inf, which is all a query with k <= KC needs: the reference's K = 20 runs the K = 32 body with
 // a 24-deep chain (three quarters of pass 1's per-candidate work).
 template <int K, int TILE_CAP, int TWG, bool WIDE = false, bool BLEND = false, bool DBL = false, int KC = K, bool BND = false>
-__global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(GridParams gp, const RecF* __restrict__ src, const uint32_t* __restrict__ cs,
+__global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : (TWG == 384 ? 3 : 4)) void knn_tile_kernel(GridParams gp, const RecF* __restrict__ src, const uint32_t* __restrict__ cs,
                                                         const RecF* __restrict__ tgt, const uint32_t* __restrict__ tblock_start, int k,
                                                         uint32_t* __restrict__ out_idx, double* __restrict__ out_d2,
                                                         uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_n, TileBlend bl, TileBlocks tb,
@@ -1316,7 +1328,7 @@ __global__ __launch_bounds__(TWG, TILE_CAP > 5000 ? 1 : 4) void knn_tile_kernel(
   static_assert(TILE_CAP < 65536, "LDS offsets are 16-bit");
 
   uint32_t b = blockIdx.x;
-  if constexpr (!WIDE) { if (tb.blocks) b = tb.blocks[blockIdx.x]; }       // (the wide variant is never run over a list)
+  if (tb.blocks) b = tb.blocks[blockIdx.x];
   const uint32_t ts = tblock_start[b], te = tblock_start[b + 1];   // (waited for only after the cell-table loads below are out)
   // block id -> cell origin of the block
   const uint32_t macro = b >> 9, m9 = b & 511u;
@@ -1994,6 +2006,23 @@ void pt_launch_mark_write(const uint8_t* mark, uint32_t m, const uint32_t* off1,
 }
 uint32_t pt_mark_tiles(uint32_t m) { return (m + CP_TILE - 1) / CP_TILE; }
 
+// ---- the blocks that hold targets, as a list (round 4): what the tile kernel is launched over on clouds that leave most of their grid
+// empty -- a surface in a fine grid has one block in a dozen occupied, and an empty block's workgroup still costs its launch and two loads
+__global__ __launch_bounds__(WG) void tblock_list_kernel(const uint32_t* __restrict__ tblock_start, uint32_t nblocks, uint32_t* __restrict__ list, uint32_t* count) {
+  const uint32_t b = blockIdx.x * WG + threadIdx.x;
+  const bool has = b < nblocks && tblock_start[b + 1] > tblock_start[b];
+  const unsigned long long mask = __ballot(has);
+  if (!mask) return;                                        // wave-uniform
+  uint32_t base = 0;
+  if ((threadIdx.x & 63) == 0) base = atomicAdd(count, (uint32_t)__popcll(mask));
+  base = (uint32_t)__shfl((int)base, 0);
+  if (has) list[base + (uint32_t)__popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull))] = b;      // (block order kept inside a wave: neighbours in the list are neighbours in the grid)
+}
+void pt_launch_tblock_list(const uint32_t* tblock_start, uint32_t nblocks, uint32_t* list, uint32_t* count, hipStream_t s) {
+  (void)hipMemsetAsync(count, 0, 4, s);
+  if (nblocks) hipLaunchKernelGGL(tblock_list_kernel, dim3((nblocks + WG - 1) / WG), dim3(WG), 0, s, tblock_start, nblocks, list, count);
+}
+
 // wave kernel over a list of `count` target positions (list == nullptr: all m targets); cell_node / nodes may be null (no refined cells)
 template <class Rec>
 void pt_launch_knn_wave(const GridParams& gp, const Rec* src, const uint32_t* cell_start, const uint32_t* cell_node, const uint32_t* nodes, uint32_t node_thr,
@@ -2067,6 +2096,12 @@ void pt_launch_knn_tile(const GridParams& gp, const RecF* src, const uint32_t* c
 #define PT_TILE_LAUNCH(KK, CAP, TH, WD) PT_TILE_LAUNCHC(KK, CAP, TH, WD, KK)
   const int small = geometry == 1;
   if (k > 24) PT_TILE_LAUNCH(32, PT_TILE_CAP_WIDE, 512, true);      // wide queue, 512 threads, one workgroup per CU
+  else if (geometry == 4 && k > 16) {
+    // MEDIUM (round 4): the K = 32 body on 384 threads and a 3888-record region -- 62 KB of LDS, six waves of <= 170 VGPRs: TWO workgroups
+    // per CU where the 768-thread geometry has one.  For clouds whose regions are small because most of their cells are empty (surfaces)
+    if (k <= 20) PT_TILE_LAUNCHC(32, PT_TILE_CAP_SMALL_16, 384, false, 20);
+    else PT_TILE_LAUNCHC(32, PT_TILE_CAP_SMALL_16, 384, false, 24);
+  }
   else if (small && k <= 16) {       // (K = 32 needs more registers than two workgroups per CU leave: large geometry only)
     if (k <= 8) PT_TILE_LAUNCH(8, PT_TILE_CAP_SMALL_8, 512, false);
     else PT_TILE_LAUNCH(16, PT_TILE_CAP_SMALL_16, 512, false);

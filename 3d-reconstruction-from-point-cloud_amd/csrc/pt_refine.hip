@@ -148,6 +148,92 @@ __global__ __launch_bounds__(RW) void refine_nodes_kernel(GridParams gp, Rec* __
   }
 }
 
+// ---- runs of identical points (pt_common.h, PT_DUP_KEEP) -------------------------------------------------------------------------
+// One workgroup per node, one WAVE per leaf sub-cell with more than PT_DUP_KEEP points (sub-cells w, w + 4, ... for wave w).  The wave
+// streams the leaf once: are all positions the first one's?  which are the 64 lowest indices? -- a sorted list, one entry per lane,
+// merged with the 64 indices of a step by a bitonic sort-merge only when one of them beats the current PT_DUP_KEEP-th (after the first
+// steps almost none does: the expected number of merges is ~ keep * ln(L / keep) / 64).  A pure leaf is then rewritten through the
+// scratch array: the keep lowest indices in ascending order, then everybody else; its child link gets the tag.
+__device__ inline uint32_t bitonic_sort64_u32(uint32_t v, int lane) {           // ascending across the 64 lanes
+#pragma unroll
+  for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+    for (int j = k2 >> 1; j >= 1; j >>= 1) {
+      const uint32_t p = (uint32_t)__shfl_xor((int)v, j);
+      const bool keep_min = ((lane & j) == 0) == ((lane & k2) == 0);
+      v = keep_min ? min(v, p) : max(v, p);
+    }
+  }
+  return v;
+}
+template <class Rec>
+__global__ __launch_bounds__(256) void dedup_leaves_kernel(Rec* __restrict__ rec, Rec* __restrict__ tmp, uint32_t n0, uint32_t* __restrict__ nodes) {
+  uint32_t* N = nodes + (size_t)(n0 + blockIdx.x) * PT_NODE_WORDS;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // Every loop of this kernel has a wave-uniform trip count and no `continue` / `break`: the body is full of cross-lane operations, and
+  // a first version that handed the leaves out through an LDS counter (`for (;;) { ... if (small) continue; ... }`) was compiled into a
+  // loop whose back-edge re-read the counter's value from a lane that had not fetched it -- sub-cell 0 for ever.
+  for (uint32_t it = 0; it < 128u; ++it) {
+    const uint32_t sub = it * 4u + wave;                    // sub-cells wave, wave + 4, ...
+    const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)N[PT_NODE_START + sub]), e = (uint32_t)__builtin_amdgcn_readfirstlane((int)N[PT_NODE_START + sub + 1]);
+    const uint32_t link = (uint32_t)__builtin_amdgcn_readfirstlane((int)N[PT_NODE_CHILD + sub]);
+    if (e - s > (uint32_t)PT_DUP_KEEP && link == 0u) {      // (link != 0: a node of the next level -- its own leaves are looked at there)
+      const Rec p0 = rec[s];
+      bool same = true;
+      uint32_t list = 0xFFFFFFFFu;                          // lane i: the i-th lowest index so far
+      for (uint32_t base = s; base < e; base += 64u) {
+        const uint32_t i = base + (uint32_t)lane;
+        uint32_t c = 0xFFFFFFFFu;
+        if (i < e) { const Rec r = rec[i]; same = same && r.x == p0.x && r.y == p0.y && r.z == p0.z; c = r.id; }
+        const uint32_t lim = (uint32_t)__shfl((int)list, PT_DUP_KEEP - 1);
+        if (__ballot(c < lim) != 0ull) {                    // wave-uniform: somebody beats the keep-th lowest
+          c = bitonic_sort64_u32(c, lane);
+          const uint32_t rv = (uint32_t)__shfl((int)c, 63 - lane);
+          list = min(list, rv);                             // the 64 lowest of list and candidates: a bitonic sequence
+#pragma unroll
+          for (int j = 32; j >= 1; j >>= 1) {
+            const uint32_t p = (uint32_t)__shfl_xor((int)list, j);
+            list = ((lane & j) == 0) ? min(list, p) : max(list, p);
+          }
+        }
+      }
+      if (__ballot(!same) == 0ull) {                        // one position only (several: the leaf is left as it is)
+        const uint32_t pivot = (uint32_t)__shfl((int)list, PT_DUP_KEEP - 1);        // the keep-th lowest index (indices are distinct)
+        if (lane < PT_DUP_KEEP) { Rec o = p0; o.id = list; tmp[s + (uint32_t)lane] = o; }
+        uint32_t w = s + (uint32_t)PT_DUP_KEEP;
+        for (uint32_t base = s; base < e; base += 64u) {
+          const uint32_t i = base + (uint32_t)lane;
+          Rec r = p0;
+          bool rest = false;
+          if (i < e) { r = rec[i]; rest = r.id > pivot; }
+          const unsigned long long m = __ballot(rest);
+          if (rest) tmp[w + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+          w += (uint32_t)__popcll(m);
+        }
+        __threadfence();                                    // (tmp is read back by other lanes of this wave below)
+        for (uint32_t base = s; base < e; base += 64u) {
+          const uint32_t i = base + (uint32_t)lane;
+          if (i < e) rec[i] = tmp[i];
+        }
+        if (lane == 0) N[PT_NODE_CHILD + sub] = PT_LEAF_TRUNC | (uint32_t)PT_DUP_KEEP;
+      }
+    }
+  }
+}
+
+// how many leaves carry the tag, and how many points sit behind their fronts (pt_stats)
+__global__ __launch_bounds__(RW) void count_tagged_leaves_kernel(uint32_t n0, const uint32_t* __restrict__ nodes, uint32_t* __restrict__ stats) {
+  const uint32_t* N = nodes + (size_t)(n0 + blockIdx.x) * PT_NODE_WORDS;
+  const uint32_t link = N[PT_NODE_CHILD + threadIdx.x];
+  const bool tagged = (link & PT_LEAF_TRUNC) != 0u;
+  uint32_t behind = tagged ? N[PT_NODE_START + threadIdx.x + 1] - N[PT_NODE_START + threadIdx.x] - (link & ~PT_LEAF_TRUNC) : 0u;
+  const uint32_t cnt = (uint32_t)__popcll(__ballot(tagged));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) behind += __shfl_xor(behind, o);
+  if ((threadIdx.x & 63) == 0 && cnt) { atomicAdd(&stats[0], cnt); atomicAdd(&stats[1], behind); }
+}
+
 // fp64 clouds: the fp32 shadow of the sorted records (id = sorted position) after refinement has moved records inside their cells
 __global__ __launch_bounds__(256) void reshadow_kernel(const RecD* __restrict__ rec, uint32_t n, RecF* __restrict__ shadow) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -176,6 +262,14 @@ void pt_launch_refine_nodes(const GridParams& gp, Rec* rec, Rec* tmp, uint32_t n
 }
 template void pt_launch_refine_nodes<RecF>(const GridParams&, RecF*, RecF*, uint32_t, uint32_t, uint32_t*, hipStream_t);
 template void pt_launch_refine_nodes<RecD>(const GridParams&, RecD*, RecD*, uint32_t, uint32_t, uint32_t*, hipStream_t);
+template <class Rec>
+void pt_launch_dedup_leaves(Rec* rec, Rec* tmp, uint32_t n0, uint32_t n1, uint32_t* nodes, uint32_t* stats2, hipStream_t s) {
+  if (n1 <= n0) return;
+  hipLaunchKernelGGL(dedup_leaves_kernel<Rec>, dim3(n1 - n0), dim3(256), 0, s, rec, tmp, n0, nodes);
+  if (stats2) hipLaunchKernelGGL(count_tagged_leaves_kernel, dim3(n1 - n0), dim3(RW), 0, s, n0, nodes, stats2);
+}
+template void pt_launch_dedup_leaves<RecF>(RecF*, RecF*, uint32_t, uint32_t, uint32_t*, uint32_t*, hipStream_t);
+template void pt_launch_dedup_leaves<RecD>(RecD*, RecD*, uint32_t, uint32_t, uint32_t*, uint32_t*, hipStream_t);
 void pt_launch_reshadow(const RecD* rec, uint32_t n, RecF* shadow, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(reshadow_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rec, n, shadow);

@@ -101,7 +101,8 @@ typedef struct pt_stats_t {
                              * the build was redone exactly; 0 exact pass 2 */
   int32_t uniform_probe;    /* last build: 1 a 1/64 sample taken before the sort found the cloud uniform (pooled pass 2 on a FIRST build), -1 it did
                              * not, 0 not asked (small cloud, one- or three-level grid, or a previous build of this cloud already knew) */
-  int32_t _pad2;
+  int32_t dup_leaves;       /* last build: leaves of refined cells found to hold ONE position more than 32 times (quantised clouds): a search reads their
+                             * 32 lowest indices only */
 } pt_stats_t;
 
 /* ---- context ------------------------------------------------------------------------ */

@@ -1580,6 +1580,67 @@ def test_wave_kernel_is_exact(pkg, oracle, kind, k, f64, thr, rho, wmin):
         assert np.array_equal(np.where(keep, want[0], 0xFFFFFFFF), bi) and np.array_equal(np.where(keep, want[1], np.inf), bd)
 
 
+@pytest.mark.parametrize("f64", [False, True])
+def test_runs_of_identical_points_keep_their_lowest_indices_in_front(pkg, oracle, f64):
+    """Quantised clouds pile thousands of points on one position.  Leaves of refined cells that hold ONE position more than 32 times are
+    rewritten -- 32 lowest indices first, ascending -- and tagged (pt_stats.dup_leaves); the wave kernel reads the front only, the group
+    kernel the whole leaf, a flat scan the whole cell: all three equal brute force under (d2, index), at k = 32 (every front entry may be
+    needed), k = 5, and under radius bounds; "dup_runs" 0 gives the same answers without the tags."""
+    import torch
+    rng = np.random.default_rng(411)
+    nodes = rng.random((3, 40)).astype(np.float32)                                      # 40 positions ...
+    mult = rng.integers(1, 900, 40)                                                     # ... 1 to 900 points each
+    src = np.repeat(nodes, mult, axis=1)
+    src = np.concatenate([src, rng.random((3, 20000)).astype(np.float32)], axis=1)      # and a thin background
+    src = src[:, rng.permutation(src.shape[1])]                                         # duplicates carry scattered indices
+    n = src.shape[1]
+    tgt = np.concatenate([nodes[:, :30] + np.float32(1e-4) * rng.standard_normal((3, 30)).astype(np.float32), nodes[:, 10:40], rng.random((3, 500)).astype(np.float32)], axis=1)
+    if f64:
+        src = src.astype(np.float64); tgt = tgt.astype(np.float64)
+    m = tgt.shape[1]
+    for k in (32, 5):
+        want = oracle.knn_bruteforce(src, tgt, k)
+        for dup, wmin, tile in ((1, 1, 0), (1, 0, 0), (0, 1, 0), (1, 1, 1)):
+            with pkg.PointsTransfer(device=0, k_hint=k) as p:
+                p.set_param("refine_threshold", 64); p.set_param("dup_runs", dup); p.set_param("tile", tile); p.set_param("wave_force", 1); p.set_param("wave_min", wmin)
+                p.build(src)
+                st = p.stats()
+                assert st["n_nodes"] > 0 and (st["dup_leaves"] > 0) == (dup == 1), st
+                _check_exact(p.query(tgt, k), want, "dup=%d wave_min=%d tile=%d k=%d" % (dup, wmin, tile, k))
+                if dup and wmin and not tile:
+                    bnd = want[1][:, k - 1].copy(); bnd[::2] *= 0.5
+                    x = torch.from_numpy(np.ascontiguousarray(tgt)).cuda(); b = torch.from_numpy(bnd).cuda()
+                    bi = torch.empty((m, k), dtype=torch.int32, device="cuda"); bd = torch.empty((m, k), dtype=torch.float64, device="cuda")
+                    p.query_bounded_dev(x, pkg.F64 if f64 else pkg.F32, b, m, k, bi, bd)
+                    torch.cuda.synchronize()
+                    keep = want[1] <= bnd[:, None]
+                    assert np.array_equal(np.where(keep, want[0], 0xFFFFFFFF), bi.cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("k,f64", [(20, False), (8, False), (24, True), (32, False)])
+def test_tile_kernel_over_the_blocks_that_hold_targets(pkg, oracle, k, f64):
+    """A surface leaves most of its grid empty: the tile kernel is then launched over a LIST of the blocks that hold targets ("tile_sparse"),
+    in the two-workgroups-per-CU geometries first -- 384 threads for k in 17..24 -- with the over-budget blocks retried in the large one,
+    and ("tile_contrast" 1) before the wave kernel on clouds whose occupied cells stay far above rho.  Same neighbours as brute force."""
+    rng = np.random.default_rng(77 + k)
+    n, m = 400_000, 6000
+    v = rng.standard_normal((3, n)); v /= np.linalg.norm(v, axis=0, keepdims=True)
+    src = (0.5 + 0.45 * v + 1e-4 * rng.standard_normal((3, n)))
+    w = rng.standard_normal((3, m)); w /= np.linalg.norm(w, axis=0, keepdims=True)
+    tgt = (0.5 + 0.45 * w + 1e-3 * rng.standard_normal((3, m)))
+    src = src.astype(np.float64 if f64 else np.float32); tgt = tgt.astype(src.dtype)
+    want = oracle.knn_bruteforce(src, tgt, k)
+    for sparse, contrast in ((1, 1), (0, 1), (2, 0)):
+        with pkg.PointsTransfer(device=0, k_hint=k) as p:
+            p.set_param("tile_sparse", sparse); p.set_param("tile_contrast", contrast)
+            p.build(src)
+            got = p.query(tgt, k)
+            st = p.stats()
+            _check_exact(got, want, "sparse=%d contrast=%d" % (sparse, contrast))
+            if contrast and k <= 24:
+                assert st["n_leftover"] < m, st                                  # the tile kernel settled some of them
+
+
 def test_config5_shape_sampled_against_oracle(pkg, oracle):
     """BASELINE config 5's own parameters at a tenth of its size: 30 M clustered points with fp16 coordinates (a lattice: hundreds of
     exact duplicates per node in the clumps), 1.5 M targets, k = 32 -- tile kernel, wave kernel and its descending variant; a

@@ -57,6 +57,10 @@ elif what == "shell":
                 p.set_param("wave_min", 0)
             if "tile" in w:
                 p.set_param("tile", 2)
+            if "tilec" in w:
+                p.set_param("tile_contrast", 1)
+            if "sparse" in w:
+                p.set_param("tile_sparse", float(w[w.index("sparse") + 1]))
             if "cpp" in w:
                 p.set_param("refine_cells_per_point", float(w[w.index("cpp") + 1]))
             if "macros" in w:
@@ -92,6 +96,8 @@ elif what in ("clus", "c5"):
                 p.set_param("refine_macros", float(w[w.index("macros") + 1]))
             if "tile" in w:
                 p.set_param("tile", float(w[w.index("tile") + 1]))
+            if "tilec" in w:
+                p.set_param("tile_contrast", 1)
             if "thr" in w:
                 p.set_param("refine_threshold", float(w[w.index("thr") + 1]))
             if "rho" in w:
