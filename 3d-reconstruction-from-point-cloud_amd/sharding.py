@@ -10,7 +10,9 @@ The reference is a single process; all of this is new design, fo
   * the (few) targets that need other slabs are exchanged with ONE all-gather of request packets, answered by the
     owning ranks with a radius-bounded search, and returned with ONE all-gather of candidate packets; the home
     rank merges its own k with the returned k's under the total order (d2, index).
-    north_star: "each GPU returning its local k candidates with an RCCL allgather over xGMI to merge".
+    north_star: "each GPU returning its local k candidates with an RCCL allgather over xGMI to merge";
+  * (round 4) the attribute table may be SHARDED with the slabs (SlabAttributes): the answers then carry their
+    candidates' records and the owner blends the completed rows from what it gathered -- per-GPU memory falls with G.
 
 Collectives are torch.distributed all_gather (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).  The
 compute steps go through a small engine interface so that the CPU tests can drive the very same protocol code
@@ -130,6 +132,51 @@ class GpuSlabEngine:
         return idx, d2
 
 
+# ---- attributes sharded with the slabs (round 4) --------------------------------------------------------------------------
+class SlabAttributes:
+    """The attribute records of ONE slab's points, kept where the points are (1/G of the table per GPU instead of a copy of all of
+    it: 16 GB at 1e9 points).  A home search only ever names points of the home slab, so its blend is local; what another slab
+    contributes arrives WITH its candidates (exchange_and_merge(..., attrs=...)): 24 bytes per candidate for the ~2 % of the targets
+    that cross a slab border.  gidx: the slab's global point indices (any order); rgb [n, 3] u8, nrm [n, 3] f32 in the same order."""
+
+    def __init__(self, gidx, rgb, nrm):
+        g = torch.as_tensor(gidx).to(torch.int64) & 0xFFFFFFFF
+        self.sorted_gidx, self.perm = torch.sort(g)
+        self.table = torch.cat([torch.as_tensor(rgb).to(torch.float64), torch.as_tensor(nrm).to(torch.float64)], dim=1).to(g.device)   # u8 / f32 are exact in f64
+
+    def lookup(self, idx_i32):
+        """[q, k] indices (u32 bit patterns; NOIDX = empty) -> [q, k, 6] records (zeros for empty entries).  Every named point must
+        belong to this slab."""
+        u = idx_i32.to(torch.int64) & 0xFFFFFFFF
+        valid = u != NOIDX
+        pos = torch.searchsorted(self.sorted_gidx, torch.where(valid, u, self.sorted_gidx[:1].expand_as(u)) if self.sorted_gidx.numel() else u)
+        pos = pos.clamp(max=max(int(self.sorted_gidx.numel()) - 1, 0))
+        if self.sorted_gidx.numel():
+            assert bool((self.sorted_gidx[pos][valid] == u[valid]).all()), "a home list names a point of another slab"
+            rec = self.table[self.perm[pos]]
+        else:
+            rec = torch.zeros(tuple(u.shape) + (6,), dtype=torch.float64, device=u.device)
+        return torch.where(valid.unsqueeze(-1), rec, torch.zeros_like(rec))
+
+
+def blend_gathered(idx_i32, d2, rec, mode=0):
+    """The blend of pt_attr.hip's blend_one from GATHERED records: rec [c, k, 6] = (r, g, b, nx, ny, nz) of the k neighbours in list
+    order, fp64 sums in that order, then one normalisation.  Returns (rgb [c, 3] f32, nrm [c, 3] f32)."""
+    valid = ((idx_i32.to(torch.int64) & 0xFFFFFFFF) != NOIDX)
+    w = torch.where(valid, (1.0 / (d2 + 1e-12)) if mode == 1 else torch.ones_like(d2), torch.zeros_like(d2))
+    acc = torch.zeros((rec.shape[0], 6), dtype=torch.float64, device=rec.device)
+    wsum = torch.zeros((rec.shape[0],), dtype=torch.float64, device=rec.device)
+    for j in range(rec.shape[1]):                                              # left to right, like the kernel
+        acc = acc + w[:, j:j + 1] * rec[:, j]
+        wsum = wsum + w[:, j]
+    has = wsum > 0
+    acc = torch.where(has.unsqueeze(1), acc / torch.where(has, wsum, torch.ones_like(wsum)).unsqueeze(1), acc)
+    nn = acc[:, 3:]
+    ln = torch.sqrt((nn * nn).sum(dim=1))
+    nn = torch.where((ln >= 1e-12).unsqueeze(1), nn / torch.where(ln >= 1e-12, ln, torch.ones_like(ln)).unsqueeze(1), nn)
+    return acc[:, :3].to(torch.float32), nn.to(torch.float32)
+
+
 # ---- the protocol ------------------------------------------------------------------------------------------------
 def _idx_to_f64(idx_i32):
     return (idx_i32.to(torch.int64) & 0xFFFFFFFF).to(torch.float64)        # u32 values are exact in f64
@@ -140,11 +187,14 @@ def _f64_to_idx(v):
     return torch.where(u >= 2**31, u - 2**32, u).to(torch.int32)          # back to the u32 bit pattern
 
 
-def exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds, on_changed=None):
+def exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds, on_changed=None, attrs=None):
     """Complete the home-slab answers (idx int32 [m,k] holding u32 bit patterns, d2 f64 [m,k], updated IN PLACE)
     with the candidates of the other slabs.  xyz: [3,m] planar coordinates of this rank's targets.
     on_changed(rows): called with the local rows whose lists were merged with foreign candidates (anything derived from
     the home-slab lists of those rows -- a fused blend -- has to be redone for them).
+    attrs (a SlabAttributes over THIS rank's slab, or None): the attribute table is sharded with the slabs -- every answer then
+    carries its candidates' records, the merge carries them along, and on_changed(rows, rec) receives rec [c, k, 6], the records of
+    the merged lists' neighbours in list order (blend_gathered turns them into the blend of those rows).
     Returns counters: targets sent out, foreign targets answered, bytes all-gathered per rank."""
     G, me = comm.world, comm.rank
     stats = {"crossing": 0, "answered": 0, "bytes_gathered": 0}
@@ -189,12 +239,15 @@ def exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds, on_changed=N
     qmax = comm.max_int(q, dev)
     if qmax == 0:            # cannot happen when cmax > 0, but never all-gather an empty tensor
         return stats
-    ans = torch.full((qmax, 2 + 2 * k), -1.0, dtype=torch.float64, device=dev)
+    aw = 6 * k if attrs is not None else 0                                  # (sharded attributes: the candidates' records ride along)
+    ans = torch.full((qmax, 2 + 2 * k + aw), -1.0, dtype=torch.float64, device=dev)
     if q:
         ans[:q, 0] = who[:, 0].to(torch.float64)
         ans[:q, 1] = who[:, 1].to(torch.float64)
         ans[:q, 2:2 + k] = ad
-        ans[:q, 2 + k:] = _idx_to_f64(ai)
+        ans[:q, 2 + k:2 + 2 * k] = _idx_to_f64(ai)
+        if aw:
+            ans[:q, 2 + 2 * k:] = attrs.lookup(ai).reshape(q, aw)
     allans = comm.all_gather(ans)                                             # [G, qmax, 2+2k]
     stats["bytes_gathered"] += allans.numel() * 8
     # -- merge what came back for my targets ----------------------------------------------------------------------
@@ -205,14 +258,34 @@ def exchange_and_merge(comm, engine, xyz, idx, d2, k, axis, bounds, on_changed=N
     li[me] = idx[sel]
     ld[me] = d2[sel]
     back = torch.nonzero(allans[:, :, 0] == float(me))                       # (server rank, row)
+    la = None
+    if attrs is not None:
+        la = torch.zeros((G, c, k, 6), dtype=torch.float64, device=dev)
+        la[me] = attrs.lookup(idx[sel])                                       # the home lists name home points only
     if back.numel():
         rec = allans[back[:, 0], back[:, 1]]
         prow = rec[:, 1].to(torch.int64)
-        li[back[:, 0], prow] = _f64_to_idx(rec[:, 2 + k:])
+        li[back[:, 0], prow] = _f64_to_idx(rec[:, 2 + k:2 + 2 * k])
         ld[back[:, 0], prow] = rec[:, 2:2 + k]
+        if la is not None:
+            la[back[:, 0], prow] = rec[:, 2 + 2 * k:].reshape(-1, k, 6)
     mi, md = engine.merge(li, ld)
     idx[sel] = mi
     d2[sel] = md
+    if la is None:
+        if on_changed is not None:
+            on_changed(sel)
+        return stats
+    # the records of the merged lists, in list order: the G * k candidates of every row ordered by (d2, index) -- two stable sorts --
+    # and cut at k; the order must be the merge's own (checked: the blend's sums run in list order)
+    ci = (li.permute(1, 0, 2).reshape(c, G * k).to(torch.int64)) & 0xFFFFFFFF
+    cd = ld.permute(1, 0, 2).reshape(c, G * k)
+    ca = la.permute(1, 0, 2, 3).reshape(c, G * k, 6)
+    o1 = torch.sort(ci, dim=1, stable=True).indices
+    o2 = torch.sort(torch.gather(cd, 1, o1), dim=1, stable=True).indices
+    order = torch.gather(o1, 1, o2)[:, :k]
+    assert bool((torch.gather(ci, 1, order) == (mi.to(torch.int64) & 0xFFFFFFFF)).all()), "attribute merge out of step with the list merge"
+    ma = torch.gather(ca, 1, order.unsqueeze(-1).expand(c, k, 6))
     if on_changed is not None:
-        on_changed(sel)
+        on_changed(sel, ma)
     return stats

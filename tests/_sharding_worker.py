@@ -81,10 +81,38 @@ def main():
     comm = sharding.TorchDistComm()
     before = idx.clone()
     changed = []
-    st = sharding.exchange_and_merge(comm, OracleSlabEngine(slab, gidx), torch.from_numpy(my_tgt), idx, d2, k, 0, bounds,
-                                     on_changed=lambda rows: changed.append(rows.clone()))
+    sharded_attrs = os.environ.get("PT_ATTRS", "0") == "1"
+    if sharded_attrs:
+        # the attribute table is sharded with the slabs: this rank holds the records of ITS points only; the home blend is local, the rows
+        # completed by other slabs are blended from the records that came with the candidates -- bit-equal to the blend over the whole table
+        rgb_all, nrm_all = O.synth_rgb(seed, n), O.synth_nrm(seed, n)
+        attrs = sharding.SlabAttributes(torch.from_numpy(gidx.astype(np.int64)), torch.from_numpy(rgb_all[mine_s]), torch.from_numpy(nrm_all[mine_s]))
+
+        def blend_from(idx_t, d2_t, rec):                       # the ORACLE's blend arithmetic on gathered records (a table of c * k rows)
+            c_ = idx_t.shape[0]
+            fake = np.arange(c_ * k, dtype=np.uint32).reshape(c_, k)
+            fake[(idx_t.numpy().view(np.uint32)) == NOIDX] = NOIDX
+            flat = rec.reshape(c_ * k, 6).numpy()
+            return O.blend(fake, d2_t.numpy(), flat[:, :3].astype(np.uint8), flat[:, 3:].astype(np.float32), mode=0)
+        rgb_out, nrm_out = blend_from(idx, d2, attrs.lookup(idx))          # home blend: local records only
+        gathered = []
+
+        def changed_cb(rows, rec):
+            changed.append(rows.clone()); gathered.append((rows.clone(), rec.clone()))
+        st = sharding.exchange_and_merge(comm, OracleSlabEngine(slab, gidx), torch.from_numpy(my_tgt), idx, d2, k, 0, bounds, on_changed=changed_cb, attrs=attrs)
+        for rows, rec in gathered:
+            r2, n2 = blend_from(idx[rows], d2[rows], rec)
+            rgb_out[rows.numpy()] = r2; nrm_out[rows.numpy()] = n2
+            pr, pn = sharding.blend_gathered(idx[rows], d2[rows], rec)     # the product's own blend of gathered records: the same within 1e-5
+            assert np.abs(pr.numpy() - r2).max(initial=0.0) / 255.0 <= 1e-5 and np.abs(pn.numpy() - n2).max(initial=0.0) <= 1e-5
+        want_rgb, want_nrm = O.blend(want_i[mine_t], want_d[mine_t], rgb_all, nrm_all, mode=0)
+        attrs_ok = np.array_equal(rgb_out, want_rgb) and np.array_equal(nrm_out, want_nrm)
+    else:
+        attrs_ok = True
+        st = sharding.exchange_and_merge(comm, OracleSlabEngine(slab, gidx), torch.from_numpy(my_tgt), idx, d2, k, 0, bounds,
+                                         on_changed=lambda rows: changed.append(rows.clone()))
     got_i = idx.numpy().view(np.uint32)
-    ok = np.array_equal(got_i, want_i[mine_t]) and np.array_equal(d2.numpy(), want_d[mine_t])
+    ok = attrs_ok and np.array_equal(got_i, want_i[mine_t]) and np.array_equal(d2.numpy(), want_d[mine_t])
     # on_changed names every row whose list was touched (what a fused blend has to redo): rows outside it are unchanged
     touched = torch.zeros(idx.shape[0], dtype=torch.bool)
     for rows in changed:

@@ -18,13 +18,17 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,case", [(2, "uniform"), (3, "uniform"), (2, "clustered"), (3, "tiny")])
-def test_slab_exchange_equals_global_knn(world, case):
+@pytest.mark.parametrize("world,case,attrs", [(2, "uniform", 0), (3, "uniform", 0), (2, "clustered", 0), (3, "tiny", 0),
+                                              (2, "uniform", 1), (3, "uniform", 1), (3, "clustered", 1), (2, "tiny", 1)])
+def test_slab_exchange_equals_global_knn(world, case, attrs):
+    """attrs = 1: the attribute table is sharded with the slabs (pt_amd.sharding.SlabAttributes) -- every rank holds its own points'
+    records only, the answers carry their candidates' records, and the blends of ALL targets equal the blend over the whole table bit
+    for bit (per-GPU memory that falls with G)."""
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   PT_CASE=case, OMP_NUM_THREADS="2")
+                   PT_CASE=case, PT_ATTRS=str(attrs), OMP_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_sharding_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
