@@ -135,7 +135,13 @@ int  pt_set_stream(pt_ctx*, void* hip_stream);
  * default: pt_rebuild of the same resident cloud starts from the cell size the previous build ended with -- checked against the
  * occupancy it finds -- instead of searching for it again; 0: every build searches from scratch), "stream_bounds" (1, default:
  * pt_stream_query searches every chunk under the bounds the targets bring and defers / skips what is out of reach; 0: every target,
- * unbounded, in every chunk -- round 2's behaviour, kept as a measurement switch). */
+ * unbounded, in every chunk -- round 2's behaviour, kept as a measurement switch).
+ * Round 4: "forget" (1: the next build of the resident cloud decides everything a FIRST build decides -- sampled bounding box, pooled
+ * passes, the uniformity sample, the cell size: what bench.py times as its cold step), "dup_runs" (1, default: leaves of refined cells
+ * that hold ONE position more than 32 times keep their 32 lowest indices in front and searches read that front only; 0 = off),
+ * "tile_sparse" (the tile kernel over a list of the blocks that hold targets: 0 never, 1 always, 2 = on clouds that leave most of
+ * their grid empty, default), "tile_contrast" (1: on clouds with strong density contrast the tile kernel runs first, k <= 24, and the
+ * wave kernel takes what it leaves; 0, default: a wave per target -- measured faster). */
 int  pt_set_param(pt_ctx*, const char* name, double value);
 const char* pt_last_error(pt_ctx*);
 int  pt_stats(pt_ctx*, pt_stats_t* out);
