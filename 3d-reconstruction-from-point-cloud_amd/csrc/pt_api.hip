@@ -1868,7 +1868,8 @@ int pt_comm_abort(pt_ctx* c) {
   if (!c) return PT_ERR_ARG;
   if (c->nccl_comm && rccl()) {
     (void)hipSetDevice(c->device);
-    if (rccl()->CommAbort) (void)rccl()->CommAbort((ncclComm_t)c->nccl_comm);     // without ncclCommAbort the communicator is leaked: never wait here
+    if (rccl()->CommAbort) (void)rccl()->CommAbort((ncclComm_t)c->nccl_comm);
+    else std::fprintf(stderr, "[pt_hip] rank %d: librccl has no ncclCommAbort: the communicator of a failed exchange is leaked rather than destroyed (a destroy could wait for peers that wait for this rank)\n", c->rank);
   }
   c->nccl_comm = nullptr; c->world = 1; c->rank = 0; c->comm_failed = false;
   return PT_OK;

@@ -62,9 +62,13 @@ def test_random_configuration_matches_oracle(pkg, oracle, case):
     # kernel, how heavy a cell must be to get a sub-grid, how fine the refinement of the cell size may go
     wforce = int(rng.random() < 0.4); wmin = int(rng.choice([1, 1, 2, 300])); thr = int(rng.choice([8192, 8192, 0, 4, 40]))
     cpp = float(rng.choice([2.0, 2.0, 0.5, 16.0]))
+    # round 4's knobs, again drawn after everything older: the tile kernel ahead of the wave kernel on clouds with density contrast, the tile
+    # kernel over the list of target-holding blocks, the fronts of leaves that hold one position many times (lattice clouds at thr 4 / 40)
+    tcon = int(rng.random() < 0.4); tsparse = int(rng.choice([2, 2, 1, 0])); dupr = int(rng.random() < 0.8)
     with pkg.PointsTransfer(device=0, **kw) as p:
         p.set_param("tile", tile); p.set_param("wave_force", wforce); p.set_param("wave_min", wmin); p.set_param("refine_threshold", thr)
         p.set_param("refine_cells_per_point", cpp)
+        p.set_param("tile_contrast", tcon); p.set_param("tile_sparse", tsparse); p.set_param("dup_runs", dupr)
         p.build(src, xyz_type=pkg.F64 if f64 else None)
         gi, gd = p.query(tgt, k, xyz_type=pkg.F64 if f64 else None)
         if case % 3 == 0:                                                  # a rebuild starts from the remembered cell size: same answer
@@ -72,7 +76,7 @@ def test_random_configuration_matches_oracle(pkg, oracle, case):
             gi2, gd2 = p.query(tgt, k, xyz_type=pkg.F64 if f64 else None)
             assert np.array_equal(gi, gi2) and np.array_equal(gd, gd2), "case %d: rebuild changed the answer" % case
     wi, wd = oracle.KdTree(src).query(tgt, k) if n else (np.full((m, k), 0xFFFFFFFF, np.uint32), np.full((m, k), np.inf))
-    what = "case %d: %s n=%d m=%d k=%d rho=%g tile=%d f64=%d wave=%d/%d thr=%d cpp=%g" % (case, kind, n, m, k, rho, tile, f64, wforce, wmin, thr, cpp)
+    what = "case %d: %s n=%d m=%d k=%d rho=%g tile=%d f64=%d wave=%d/%d thr=%d cpp=%g tcon=%d tsparse=%d dup=%d" % (case, kind, n, m, k, rho, tile, f64, wforce, wmin, thr, cpp, tcon, tsparse, dupr)
     assert np.array_equal(gi, wi), what + ": indices differ in %d rows" % int((gi != wi).any(axis=1).sum())
     assert np.array_equal(gd, wd), what + ": d2 differ"
 
