@@ -19,7 +19,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_UNSUPPORTED = 0, -1, -2, -3, -4,
 # every symbol include/pt_api.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "pt_ctx_create", "pt_ctx_destroy", "pt_set_stream", "pt_set_param", "pt_last_error", "pt_stats", "pt_synchronize",
-    "pt_build_aos", "pt_build_soa", "pt_build_soa_indexed", "pt_set_attributes", "pt_set_attributes_range", "pt_build_synth", "pt_rebuild",
+    "pt_build_aos", "pt_build_soa", "pt_build_soa_indexed", "pt_set_attributes", "pt_set_attributes_range", "pt_set_attributes_local", "pt_build_synth", "pt_rebuild",
     "pt_num_source", "pt_query_aos", "pt_query_soa", "pt_targets_synth", "pt_targets_soa", "pt_targets_aos", "pt_num_targets", "pt_query_resident", "pt_query_blend_resident", "pt_query_resident_host",
     "pt_resident_target_ids", "pt_resident_target_xyz", "pt_resident_source_xyz", "pt_blend", "pt_blend_dev", "pt_blend_weighted", "pt_blend_weighted_dev", "pt_pca_normals",
     "pt_pca_normals_dev", "pt_merge_candidates_dev", "pt_slab_need_dev", "pt_pack_requests_dev", "pt_query_bounded_dev",
@@ -82,6 +82,7 @@ def lib():
         "pt_build_soa_indexed": (i32, [p, p, i32, p, u64, i32]),
         "pt_set_attributes": (i32, [p, p, p, u64, i32]),
         "pt_set_attributes_range": (i32, [p, u64, u64, p, p, u64]),
+        "pt_set_attributes_local": (i32, [p, p, p, i32]),
         "pt_build_synth": (i32, [p, u64, u64, i32, i32, i32, dbl, dbl]),
         "pt_rebuild": (i32, [p]),
         "pt_num_source": (u64, [p]),

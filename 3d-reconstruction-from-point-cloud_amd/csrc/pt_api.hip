@@ -63,6 +63,9 @@ struct pt_ctx {
   float e_src = 0.f;           // fp64 clouds: largest rounding error of a source coordinate stored as fp32
   DevBuf posattr;              // fp32 clouds: {position, attributes} by original index for the PCA pass, built on first use
   bool has_gidx = false, has_attr = false, built = false, posattr_valid = false;
+  // slabs (round 4): "local_ids" asked for AND the slab's gidx strictly ascending -> the records carry the point's POSITION in the slab's arrays
+  // (same order as the global index), the attribute table may be the slab's own n records (attr_local), finished lists are translated through gidx
+  bool want_local_ids = false, local_mode = false, attr_local = false;
   uint64_t guess_min_points = 8u << 20;   // clouds at least this large lay their grid out from a sampled bounding box
   bool bbox_guess_ok = true;   // big clouds: lay the grid out from a sampled bounding box (cleared when a guess failed; reset by an upload)
   bool stream_bounds = true;   // pt_stream_query: later chunks are searched under the targets' current k-th distances and skipped when out of reach ("stream_bounds", a measurement switch)
@@ -106,6 +109,7 @@ struct pt_ctx {
   hipEvent_t xev[2] = {nullptr, nullptr};                     // exchange timing (run_query uses ev[0..2] itself)
   int world = 1, rank = 0;
   DevBuf x_bounds, x_counts, x_matrix, x_off, x_req, x_row, x_rreq, x_rxyz, x_rbound, x_ans_i, x_ans_d, x_back_i, x_back_d, x_flags, x_rows;
+  DevBuf x_ans_a, x_back_a, x_rattr, l_idx;                 // sharded attributes: the candidates' records out and back, the merged rows' records; a list translated back to local ids
   std::vector<uint32_t> x_send, x_recv, x_soff, x_roff;      // per peer: packets to send / to answer, and their offsets
   uint32_t* h_matrix = nullptr;                               // pinned, world * world
   uint32_t* h_xoff = nullptr;                                 // pinned staging of the send offsets (xb_fill)
@@ -269,7 +273,7 @@ int run_source_sort(pt_ctx* c, uint64_t* bbox6_verify) {
   const T* x = (const T*)c->in_xyz.p;
   hipError_t e = hipSuccess;
   c->stb.status = &e;
-  const Rec* r = pt_launch_grid_sort<T, Rec>(c->gp, x, x + c->n, x + 2 * c->n, c->has_gidx ? (const uint32_t*)c->in_gidx.p : nullptr, (uint32_t)c->n,
+  const Rec* r = pt_launch_grid_sort<T, Rec>(c->gp, x, x + c->n, x + 2 * c->n, (c->has_gidx && !c->local_mode) ? (const uint32_t*)c->in_gidx.p : nullptr, (uint32_t)c->n,
                                              (Rec*)c->rec.p, (Rec*)c->rec_tmp.p, (uint32_t*)c->cell_start.p, c->stb, true, c->stream, bbox6_verify);
   c->stb.status = nullptr;
   if (!r) return fail(c, PT_ERR_HIP, "grid build: a launch of the sort failed: %s", hipGetErrorString(e));
@@ -824,6 +828,7 @@ int run_query(pt_ctx* c, const void* txyz, int ttype, uint64_t tm, int k, const 
       if (br && !wave_blended) pt_launch_blend(idx_dev, d2_dev, m, k, br->mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, br->rgb_out, br->nrm_out, c->stream);
     }
   }
+  if (c->local_mode && m) pt_launch_ids_to_global(idx_dev, (size_t)m * (size_t)k, (const uint32_t*)c->in_gidx.p, c->stream);      // positions in the slab -> global indices (every blend above used the positions)
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, hipGetLastError());
   c->st.n_target = m;
@@ -917,7 +922,7 @@ void pt_ctx_destroy(pt_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in_xyz, &c->in_gidx, &c->attr, &c->rec, &c->rec_tmp, &c->cell_start, &c->stb_mem, &c->t_xyz, &c->t_gidx, &c->trec,
                    &c->trec_tmp, &c->x_xyz, &c->ttb_mem, &c->bbox6, &c->counter, &c->q_idx, &c->q_d2, &c->b_rgb, &c->b_nrm, &c->aos_stage, &c->misc, &c->bounds, &c->todo, &c->posattr, &c->retry, &c->rec32, &c->up_rgb, &c->up_nrm, &c->x_bounds, &c->x_counts, &c->x_matrix, &c->x_off, &c->x_req, &c->x_row, &c->x_rreq,
-                   &c->x_rxyz, &c->x_rbound, &c->x_ans_i, &c->x_ans_d, &c->x_back_i, &c->x_back_d, &c->x_flags, &c->x_rows, &c->cell_node, &c->nodes, &c->heavy, &c->near_node, &c->xyz32, &c->tlist};
+                   &c->x_rxyz, &c->x_rbound, &c->x_ans_i, &c->x_ans_d, &c->x_back_i, &c->x_back_d, &c->x_flags, &c->x_rows, &c->cell_node, &c->nodes, &c->heavy, &c->near_node, &c->xyz32, &c->tlist, &c->x_ans_a, &c->x_back_a, &c->x_rattr, &c->l_idx};
   for (DevBuf* b : all) release(c, *b);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->h_counter) (void)hipHostFree(c->h_counter);
@@ -956,6 +961,7 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
   if (!strcmp(name, "tile")) { c->tile = (int)value; return PT_OK; }
   if (!strcmp(name, "tile_sparse")) { c->tile_sparse = (int)value; return PT_OK; }
   if (!strcmp(name, "dup_runs")) { c->dup_runs = value != 0; return PT_OK; }
+  if (!strcmp(name, "local_ids")) { c->want_local_ids = value != 0; return PT_OK; }      // before pt_build_soa_indexed: see pt_set_attributes_local
   if (!strcmp(name, "tile_contrast")) { c->tile_contrast = (int)value; return PT_OK; }
   if (!strcmp(name, "grid_hint")) { c->grid_hint = value != 0; if (!c->grid_hint) c->hint_h = 0.0; return PT_OK; }
   if (!strcmp(name, "refine_cells_per_point")) { if (!(value > 0 && value <= 1e6)) return fail(c, PT_ERR_ARG, "refine_cells_per_point out of range"); c->refine_cpp = value; return PT_OK; }
@@ -1004,7 +1010,7 @@ int pt_build_aos(pt_ctx* c, const pt_point* cloud, uint64_t n) {
   { int r = copy_in(c, c->aos_stage.p, cloud, n * sizeof(pt_point), 0); if (r) return r; }
   double* x = (double*)c->in_xyz.p;
   pt_launch_aos_split(c->aos_stage.p, (uint32_t)n, x, x + n, x + 2 * n, (Attr*)c->attr.p, c->stream);
-  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
+  c->src_type = PT_F64; c->n = n; c->n_total = n; c->has_gidx = false; c->local_mode = false; c->attr_local = false; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -1026,13 +1032,45 @@ int pt_build_soa_indexed(pt_ctx* c, const void* xyz, int xyz_type, const uint32_
     { int r = copy_in(c, c->in_gidx.p, gidx, n * sizeof(uint32_t), on_device); if (r) return r; }
   }
   c->src_type = xyz_type; c->n = n; c->has_gidx = gidx != nullptr; c->built = false;
-  if (!gidx) { c->n_total = n; c->has_attr = false; }
+  c->local_mode = false;
+  if (gidx && c->want_local_ids) {
+    uint32_t* flag = (uint32_t*)c->counter.p + 1;
+    HIPCHK(c, hipMemsetAsync(flag, 0, 4, c->stream));
+    pt_launch_ascending((const uint32_t*)c->in_gidx.p, (uint32_t)n, flag, c->stream);
+    HIPCHK(c, hipMemcpyAsync(c->h_counter + 1, flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_counter[1]) return fail(c, PT_ERR_ARG, "local_ids: the slab's global indices must be strictly ascending (positions then order like indices)");
+    c->local_mode = true;
+    c->has_attr = false; c->attr_local = false;
+  }
+  if (!gidx) { c->n_total = n; c->has_attr = false; c->attr_local = false; }
   c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
   return rebuild(c);
 }
 
+int pt_set_attributes_local(pt_ctx* c, const uint8_t* rgb, const float* nrm, int on_device) {
+  if (!c) return PT_ERR_ARG;
+  if (!c->local_mode) return fail(c, PT_ERR_STATE, "pt_set_attributes_local: build the slab with pt_set_param(\"local_ids\", 1) and ascending global indices first");
+  const uint64_t n = c->n;
+  HIPCHK(c, hipSetDevice(c->device));
+  RES(c, c->attr, std::max<uint64_t>(n, 1) * sizeof(Attr));
+  const uint8_t* drgb = rgb;
+  const float* dnrm = nrm;
+  if (!on_device) {
+    RES(c, c->misc, std::max<uint64_t>(n, 1) * 15);
+    uint8_t* base = (uint8_t*)c->misc.p;
+    if (nrm) { int r = copy_in(c, base, nrm, n * 12, 0); if (r) return r; dnrm = (const float*)base; }
+    if (rgb) { int r = copy_in(c, base + n * 12, rgb, n * 3, 0); if (r) return r; drgb = base + n * 12; }
+  }
+  pt_launch_pack_attr(drgb, dnrm, (uint32_t)n, (Attr*)c->attr.p, c->stream);
+  c->n_total = n;                      // the table's size: the slab's own points
+  c->has_attr = true; c->attr_local = true; c->posattr_valid = false;
+  return finish(c);
+}
+
 int pt_set_attributes(pt_ctx* c, const uint8_t* rgb, const float* nrm, uint64_t n_total, int on_device) {
   if (!c) return PT_ERR_ARG;
+  if (c->local_mode) return fail(c, PT_ERR_STATE, "this slab keeps local ids: its attribute table is pt_set_attributes_local's (its own points' records)");
   { int r = check_n(c, n_total, "n_total"); if (r) return r; }
   HIPCHK(c, hipSetDevice(c->device));
   RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
@@ -1052,6 +1090,7 @@ int pt_set_attributes(pt_ctx* c, const uint8_t* rgb, const float* nrm, uint64_t 
 
 int pt_set_attributes_range(pt_ctx* c, uint64_t first, uint64_t count, const uint8_t* rgb, const float* nrm, uint64_t n_total) {
   if (!c) return PT_ERR_ARG;
+  if (c->local_mode) return fail(c, PT_ERR_STATE, "this slab keeps local ids: its attribute table is pt_set_attributes_local's (its own points' records)");
   { int r = check_n(c, n_total, "n_total"); if (r) return r; }
   if (first > n_total || count > n_total - first) return fail(c, PT_ERR_ARG, "pt_set_attributes_range: [first, first + count) outside the table of n_total records");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1092,7 +1131,23 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
   HIPCHK(c, hipSetDevice(c->device));
   uint64_t n = n_total;
   const bool slab = slab_axis >= 0;
-  if (slab) {   // counting pass
+  // "local_ids": the slab is generated in INDEX ORDER (per-workgroup counts, a scan, ranked writes: pt_attr.hip) so that its records can
+  // carry positions, and its attribute table holds its own points only
+  const bool ordered = slab && c->want_local_ids;
+  uint32_t *wg_cnt = nullptr, *wg_off = nullptr;
+  const uint32_t nwg = (uint32_t)((n_total + 255) / 256);
+  if (ordered) {
+    RES(c, c->misc, ((size_t)nwg + 8) * 2 * sizeof(uint32_t) + ((size_t)nwg / 2048 + 16) * sizeof(uint32_t));
+    wg_cnt = (uint32_t*)c->misc.p; wg_off = wg_cnt + nwg + 8;
+    uint32_t* scan_tmp = wg_off + nwg + 8;
+    HIPCHK(c, hipMemsetAsync(wg_cnt + nwg, 0, 4, c->stream));
+    pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, nullptr, nullptr, nullptr, nullptr, nullptr, 0, f16, dist, n_total, 0, c->stream, wg_cnt, nullptr);
+    pt_launch_scan_u32(wg_cnt, wg_off, nwg + 1, scan_tmp, c->stream);
+    HIPCHK(c, hipMemcpyAsync(c->h_counter, wg_off + nwg, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    n = *c->h_counter;
+    RES(c, c->in_gidx, std::max<uint64_t>(n, 1) * sizeof(uint32_t));
+  } else if (slab) {   // counting pass
     HIPCHK(c, hipMemsetAsync(c->counter.p, 0, 4, c->stream));
     pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, nullptr, nullptr, nullptr, nullptr, (uint32_t*)c->counter.p, 0, f16, dist, n_total, 0, c->stream);
     HIPCHK(c, hipMemcpyAsync(c->h_counter, c->counter.p, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1104,12 +1159,17 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
   const bool keep_half = f16 != 0;
   RES(c, c->in_xyz, std::max<uint64_t>(n, 1) * 3 * (keep_half ? sizeof(__half) : tsize(xyz_type)));
   uint32_t* g = slab ? (uint32_t*)c->in_gidx.p : nullptr;
-  if (keep_half) { __half* x = (__half*)c->in_xyz.p; pt_launch_synth_xyz<__half>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, 1, dist, n_total, 0, c->stream); }
-  else if (xyz_type == PT_F32) { float* x = (float*)c->in_xyz.p; pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream); }
-  else { double* x = (double*)c->in_xyz.p; pt_launch_synth_xyz<double>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream); }
-  RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
-  pt_launch_synth_attr(seed, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
-  c->src_type = xyz_type; c->n = n; c->n_total = n_total; c->has_gidx = slab; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
+  if (keep_half) { __half* x = (__half*)c->in_xyz.p; pt_launch_synth_xyz<__half>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, 1, dist, n_total, 0, c->stream, nullptr, ordered ? wg_off : nullptr); }
+  else if (xyz_type == PT_F32) { float* x = (float*)c->in_xyz.p; pt_launch_synth_xyz<float>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream, nullptr, ordered ? wg_off : nullptr); }
+  else { double* x = (double*)c->in_xyz.p; pt_launch_synth_xyz<double>(seed, 0, (uint32_t)n_total, slab_axis, slab_lo, slab_hi, x, x + n, x + 2 * n, g, (uint32_t*)c->counter.p, (uint32_t)n, f16, dist, n_total, 0, c->stream, nullptr, ordered ? wg_off : nullptr); }
+  if (ordered) {                                   // the slab's own records only: 16 n bytes instead of 16 n_total
+    RES(c, c->attr, std::max<uint64_t>(n, 1) * sizeof(Attr));
+    pt_launch_synth_attr(seed, (uint32_t)n, (Attr*)c->attr.p, c->stream, (const uint32_t*)c->in_gidx.p);
+  } else {
+    RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
+    pt_launch_synth_attr(seed, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
+  }
+  c->src_type = xyz_type; c->n = n; c->n_total = ordered ? n : n_total; c->has_gidx = slab; c->local_mode = ordered; c->attr_local = ordered; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -1296,6 +1356,13 @@ int pt_blend_dev(pt_ctx* c, const uint32_t* idx_dev, const double* d2_dev_or_nul
   if (m && !idx_dev) return fail(c, PT_ERR_ARG, "idx is null");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (c->attr_local) {
+    // the table holds this slab's points by POSITION: the lists' global indices are looked up in the slab's ascending gidx; an entry that
+    // names another slab's point (a row the exchange completed) cannot be blended from here -- pt_exchange_merge_* re-blends those rows itself
+    RES(c, c->l_idx, std::max<uint64_t>(m, 1) * k * sizeof(uint32_t));
+    pt_launch_ids_to_local(idx_dev, (size_t)m * k, (const uint32_t*)c->in_gidx.p, (uint32_t)c->n, (uint32_t*)c->l_idx.p, c->stream);
+    idx_dev = (const uint32_t*)c->l_idx.p;
+  }
   pt_launch_blend(idx_dev, d2_dev_or_null, (uint32_t)m, k, mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, rgb_out_dev, nrm_out_dev, c->stream);
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   HIPCHK(c, hipGetLastError());
@@ -1337,6 +1404,11 @@ int pt_blend_weighted_dev(pt_ctx* c, const uint32_t* idx_dev, const double* w_de
   if (k < 1 || k > PT_MAX_K) return fail(c, PT_ERR_ARG, "k out of range");
   if (m && (!idx_dev || !w_dev)) return fail(c, PT_ERR_ARG, "null argument");
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->attr_local) {                                       // (as pt_blend_dev: global indices -> positions in this slab's table)
+    RES(c, c->l_idx, std::max<uint64_t>(m, 1) * k * sizeof(uint32_t));
+    pt_launch_ids_to_local(idx_dev, (size_t)m * k, (const uint32_t*)c->in_gidx.p, (uint32_t)c->n, (uint32_t*)c->l_idx.p, c->stream);
+    idx_dev = (const uint32_t*)c->l_idx.p;
+  }
   pt_launch_blend_weighted(idx_dev, w_dev, (uint32_t)m, k, (const Attr*)c->attr.p, (uint32_t)c->n_total, rgb_out_dev, nrm_out_dev, c->stream);
   HIPCHK(c, hipGetLastError());
   return finish(c);
@@ -1518,7 +1590,7 @@ int pt_upload_end(pt_ctx* c) {
   const uint64_t n = c->up_n;
   if (c->up_attr) pt_launch_pack_attr((const uint8_t*)c->up_rgb.p, (const float*)c->up_nrm.p, (uint32_t)n, (Attr*)c->attr.p, c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));                                // the caller's buffers are free again
-  c->src_type = c->up_type; c->n = n; c->n_total = n; c->has_gidx = false; c->has_attr = c->up_attr != 0; c->built = false;
+  c->src_type = c->up_type; c->n = n; c->n_total = n; c->has_gidx = false; c->local_mode = false; c->attr_local = false; c->has_attr = c->up_attr != 0; c->built = false;
   c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
   c->up_type = -1;
   release(c, c->up_rgb); release(c, c->up_nrm);
@@ -1595,7 +1667,7 @@ int pt_stream_query(pt_ctx* c, const void* xyz, int xyz_type, uint64_t n, uint64
     auto adopt = [&](uint64_t ch, int b) {
       const uint64_t f0 = ch * chunk_points, cnt = std::min<uint64_t>(chunk_points, n - f0);
       c->in_xyz = stage[b];
-      c->src_type = xyz_type; c->n = cnt; c->n_total = cnt; c->has_gidx = false; c->has_attr = false; c->built = false;
+      c->src_type = xyz_type; c->n = cnt; c->n_total = cnt; c->has_gidx = false; c->local_mode = false; c->attr_local = false; c->has_attr = false; c->built = false;
       c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; c->in_half = false; c->xyz32_valid = false;
     };
     auto bounds_and_reach = [&](uint64_t ch, int backward, uint32_t& reach) -> int {
@@ -1770,6 +1842,7 @@ int xb_fill(pt_ctx* c, const XArgs& A, const uint32_t* matrix) {
   RES(c, c->x_rreq, std::max<size_t>(R, 1) * 32);
   RES(c, c->x_back_i, std::max<size_t>(S, 1) * (size_t)A.k * 4); RES(c, c->x_back_d, std::max<size_t>(S, 1) * (size_t)A.k * 8);
   RES(c, c->x_ans_i, std::max<size_t>(R, 1) * (size_t)A.k * 4); RES(c, c->x_ans_d, std::max<size_t>(R, 1) * (size_t)A.k * 8);
+  if (c->attr_local) { RES(c, c->x_ans_a, std::max<size_t>(R, 1) * (size_t)A.k * sizeof(Attr)); RES(c, c->x_back_a, std::max<size_t>(S, 1) * (size_t)A.k * sizeof(Attr)); }
   uint32_t* off = (uint32_t*)c->x_off.p;
   uint32_t* cursor = off + 65;
   // the offsets travel from PINNED memory, so the copy needs no host wait; the event says when the staging words may be rewritten
@@ -1794,30 +1867,42 @@ int xc_answer(pt_ctx* c, const XArgs& A) {
   RES(c, c->x_rxyz, (size_t)R * 3 * tsize(A.type)); RES(c, c->x_rbound, (size_t)R * 8);
   if (A.type == PT_F32) pt_launch_xunpack<float>((const double*)c->x_rreq.p, R, (float*)c->x_rxyz.p, (double*)c->x_rbound.p, c->stream);
   else pt_launch_xunpack<double>((const double*)c->x_rreq.p, R, (double*)c->x_rxyz.p, (double*)c->x_rbound.p, c->stream);
-  return run_query(c, c->x_rxyz.p, A.type, R, A.k, (const double*)c->x_rbound.p, (uint32_t*)c->x_ans_i.p, (double*)c->x_ans_d.p);
+  { int r = run_query(c, c->x_rxyz.p, A.type, R, A.k, (const double*)c->x_rbound.p, (uint32_t*)c->x_ans_i.p, (double*)c->x_ans_d.p); if (r) return r; }
+  // attribute table sharded with the slabs: the candidates' records ride along (they are this slab's points: found by position in its ascending gidx)
+  if (c->attr_local && c->has_attr)
+    pt_launch_xgather_attr((const uint32_t*)c->x_ans_i.p, (size_t)R * (size_t)A.k, (const uint32_t*)c->in_gidx.p, (uint32_t)c->n, (const Attr*)c->attr.p, (Attr*)c->x_ans_a.p, c->stream);
+  return PT_OK;
 }
 // phase d: merge what came back (x_back_*, bucket by bucket) and redo the blend of the completed rows
 int xd_merge(pt_ctx* c, const XArgs& A, int blend_mode, float* rgb, float* nrm) {
   const uint32_t S = c->x_soff[(size_t)A.g];
   if (!S) return PT_OK;
   const bool reblend = blend_mode >= 0 && (rgb || nrm) && c->has_attr;
+  const bool sharded = reblend && c->attr_local;        // the table holds this slab's points only: the merge carries the candidates' records along
   uint8_t* flags = nullptr;
   if (reblend) {
     RES(c, c->x_flags, std::max<size_t>(A.m, 1)); RES(c, c->x_rows, (std::max<size_t>(A.m, 1) + 4) * 4);
     flags = (uint8_t*)c->x_flags.p;
     HIPCHK(c, hipMemsetAsync(flags, 0, A.m, c->stream));
   }
+  if (sharded) RES(c, c->x_rattr, std::max<size_t>(A.m, 1) * (size_t)A.k * sizeof(Attr));      // (rows the exchange touches: written before they are read)
   for (int p = 0; p < A.g; ++p) {                     // one launch per bucket: a row may sit in two buckets (both neighbours)
     const uint32_t cnt = c->x_send[(size_t)p], o = c->x_soff[(size_t)p];
-    pt_launch_xmerge((const uint32_t*)c->x_row.p + o, cnt, (const uint32_t*)c->x_back_i.p + (size_t)o * A.k, (const double*)c->x_back_d.p + (size_t)o * A.k, A.k,
-                     A.idx, A.d2, flags, c->stream);
+    if (sharded)
+      pt_launch_xmerge_attr((const uint32_t*)c->x_row.p + o, cnt, (const uint32_t*)c->x_back_i.p + (size_t)o * A.k, (const double*)c->x_back_d.p + (size_t)o * A.k,
+                            (const Attr*)c->x_back_a.p + (size_t)o * A.k, A.k, A.idx, A.d2, (Attr*)c->x_rattr.p, flags, (const uint32_t*)c->in_gidx.p, (uint32_t)c->n,
+                            (const Attr*)c->attr.p, c->stream);
+    else
+      pt_launch_xmerge((const uint32_t*)c->x_row.p + o, cnt, (const uint32_t*)c->x_back_i.p + (size_t)o * A.k, (const double*)c->x_back_d.p + (size_t)o * A.k, A.k,
+                       A.idx, A.d2, flags, c->stream);
   }
   if (reblend) {
     uint32_t* rows = (uint32_t*)c->x_rows.p;
     uint32_t* rows_n = rows + std::max<size_t>(A.m, 1);
     HIPCHK(c, hipMemsetAsync(rows_n, 0, 4, c->stream));
     pt_launch_xflag_rows(flags, A.m, rows, rows_n, c->stream);
-    pt_launch_blend_rows(rows, rows_n, std::min<uint32_t>(A.m, S), A.idx, A.d2, A.k, blend_mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, rgb, nrm, c->stream);
+    if (sharded) pt_launch_blend_rows_attr(rows, rows_n, std::min<uint32_t>(A.m, S), A.idx, A.d2, (const Attr*)c->x_rattr.p, A.k, blend_mode, rgb, nrm, c->stream);
+    else pt_launch_blend_rows(rows, rows_n, std::min<uint32_t>(A.m, S), A.idx, A.d2, A.k, blend_mode, (const Attr*)c->attr.p, (uint32_t)c->n_total, rgb, nrm, c->stream);
   }
   HIPCHK(c, hipGetLastError());
   return PT_OK;
@@ -1915,6 +2000,10 @@ int pt_exchange_merge_dev(pt_ctx* c, const void* tgt_xyz_dev, int xyz_type, uint
       const size_t ro = (size_t)c->x_roff[(size_t)p] * k, rc = (size_t)c->x_recv[(size_t)p] * k, so = (size_t)c->x_soff[(size_t)p] * k, sc = (size_t)c->x_send[(size_t)p] * k;
       if (rc) { NCCLGRP(gerr, gwhat, rccl()->Send((const uint32_t*)c->x_ans_i.p + ro, rc, ncclUint32, p, comm, c->stream)); NCCLGRP(gerr, gwhat, rccl()->Send((const double*)c->x_ans_d.p + ro, rc, ncclFloat64, p, comm, c->stream)); }
       if (sc) { NCCLGRP(gerr, gwhat, rccl()->Recv((uint32_t*)c->x_back_i.p + so, sc, ncclUint32, p, comm, c->stream)); NCCLGRP(gerr, gwhat, rccl()->Recv((double*)c->x_back_d.p + so, sc, ncclFloat64, p, comm, c->stream)); }
+      if (c->attr_local) {      // (every rank of a job runs the same mode: the candidates' 16-byte records as four words each)
+        if (rc) NCCLGRP(gerr, gwhat, rccl()->Send((const uint32_t*)c->x_ans_a.p + ro * 4, rc * 4, ncclUint32, p, comm, c->stream));
+        if (sc) NCCLGRP(gerr, gwhat, rccl()->Recv((uint32_t*)c->x_back_a.p + so * 4, sc * 4, ncclUint32, p, comm, c->stream));
+      }
     }
     NCCLGRP(gerr, gwhat, rccl()->GroupEnd());
     if (gerr != ncclSuccess) { if (gwhat[0] && !strstr(gwhat, "GroupEnd")) (void)rccl()->GroupEnd(); return rccl_fail(c, gwhat, gerr); }
@@ -1928,7 +2017,8 @@ int pt_exchange_merge_dev(pt_ctx* c, const void* tgt_xyz_dev, int xyz_type, uint
   if (st) {
     const uint64_t S = c->x_soff[(size_t)g], R = c->x_roff[(size_t)g];
     st->crossing = S; st->answered = R;
-    st->bytes_sent = S * 32 + R * (uint64_t)k * 12; st->bytes_received = R * 32 + S * (uint64_t)k * 12;
+    const uint64_t cand = c->attr_local ? 28 : 12;        // (index + distance, + the attribute record when the table is sharded)
+    st->bytes_sent = S * 32 + R * (uint64_t)k * cand; st->bytes_received = R * 32 + S * (uint64_t)k * cand;
   }
   if (c->sync || st) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2013,6 +2103,7 @@ int pt_exchange_merge_local(pt_ctx* const* ctxs, int g, const void* const* tgt_x
         const size_t ro = (size_t)a->x_roff[(size_t)p] * k, cnt = (size_t)a->x_recv[(size_t)p] * k, so = (size_t)b->x_soff[(size_t)r] * k;
         HIPCHK(a, hipMemcpyAsync((uint32_t*)b->x_back_i.p + so, (const uint32_t*)a->x_ans_i.p + ro, cnt * 4, hipMemcpyDeviceToDevice, a->stream));
         HIPCHK(a, hipMemcpyAsync((double*)b->x_back_d.p + so, (const double*)a->x_ans_d.p + ro, cnt * 8, hipMemcpyDeviceToDevice, a->stream));
+        if (a->attr_local && b->attr_local) HIPCHK(a, hipMemcpyAsync((Attr*)b->x_back_a.p + so, (const Attr*)a->x_ans_a.p + ro, cnt * sizeof(Attr), hipMemcpyDeviceToDevice, a->stream));
       }
     { int e = all_sync(); if (e) return e; }
     for (int r = 0; r < g; ++r) { int e = xd_merge(ctxs[r], A[(size_t)r], blend_mode, rgb_dev ? rgb_dev[r] : nullptr, nrm_dev ? nrm_dev[r] : nullptr); if (e) return e; }

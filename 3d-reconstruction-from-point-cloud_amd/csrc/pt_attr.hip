@@ -60,11 +60,19 @@ template <class T>
 __global__ __launch_bounds__(WG) void synth_xyz_kernel(uint64_t key, uint32_t n_total, int axis, double lo, double hi, T* __restrict__ x,
                                                        T* __restrict__ y, T* __restrict__ z, uint32_t* __restrict__ gidx, uint32_t* counter,
                                                        uint32_t capacity, int round_f16, int dist, uint64_t seed, int stream,
-                                                       uint64_t src_total, uint64_t tgt_total) {
+                                                       uint64_t src_total, uint64_t tgt_total, uint32_t* __restrict__ wg_cnt, const uint32_t* __restrict__ wg_off) {
 #pragma clang fp contract(off)
+  // ORDERED slabs (round 4; wg_cnt / wg_off): the points of a slab keep the order of their global indices -- every workgroup of 256
+  // consecutive indices counts its members (first launch: wg_cnt), the counts are scanned, and the second launch (wg_off) writes each
+  // member at its workgroup's offset + its rank inside the workgroup.  Ascending indices are what lets a slab carry positions in its
+  // records (pt_exchange.hip).  Without either the members are appended through one atomic counter, in any order.
+  __shared__ uint32_t wsum[4];
+  const bool ordered = wg_cnt != nullptr || wg_off != nullptr;
   const uint32_t i = blockIdx.x * WG + threadIdx.x;
-  if (i >= n_total) return;
-  float px, py, pz;
+  if (i >= n_total && !ordered) return;
+  const bool live = i < n_total;
+  float px = 0.f, py = 0.f, pz = 0.f;
+  if (live) {
   if (dist == 0) {
     px = u24(splitmix64(key + 4ull * i + 0));
     py = u24(splitmix64(key + 4ull * i + 1));
@@ -83,21 +91,34 @@ __global__ __launch_bounds__(WG) void synth_xyz_kernel(uint64_t key, uint32_t n_
   if (round_f16) {   // BASELINE config 5: xyz = half_rn(fp32 value), widened back exactly
     px = __half2float(__float2half_rn(px)); py = __half2float(__float2half_rn(py)); pz = __half2float(__float2half_rn(pz));
   }
+  }
   uint32_t pos = i;
   if (axis >= 0) {
     const double c = (double)(axis == 0 ? px : (axis == 1 ? py : pz));
-    if (!(c >= lo && c < hi)) return;
-    pos = atomicAdd(counter, 1u);      // hipcc folds this into one atomic per wave
-    if (!x || pos >= capacity) return;   // counting pass, or overflow (host checks the counter)
+    const bool in = live && c >= lo && c < hi;
+    if (ordered) {
+      uint32_t tot;
+      const uint32_t rank = block_excl_scan(in ? 1u : 0u, wsum, tot);
+      if (wg_cnt) { if (threadIdx.x == 0) wg_cnt[blockIdx.x] = tot; return; }
+      if (!in) return;
+      pos = wg_off[blockIdx.x] + rank;
+      if (!x || pos >= capacity) return;
+    } else {
+      if (!in) return;
+      pos = atomicAdd(counter, 1u);      // hipcc folds this into one atomic per wave
+      if (!x || pos >= capacity) return;   // counting pass, or overflow (host checks the counter)
+    }
   }
   x[pos] = (T)px; y[pos] = (T)py; z[pos] = (T)pz;
   if (gidx) gidx[pos] = i;
 }
 
-__global__ __launch_bounds__(WG) void synth_attr_kernel(uint64_t key_rgb, uint64_t key_nrm, uint32_t n_total, Attr* __restrict__ attr) {
+// gidx != null: attr[j] is the record of point gidx[j] (a slab's own table, in the slab's order); else attr[i] of point i
+__global__ __launch_bounds__(WG) void synth_attr_kernel(uint64_t key_rgb, uint64_t key_nrm, uint32_t n_total, Attr* __restrict__ attr, const uint32_t* __restrict__ gidx) {
 #pragma clang fp contract(off)
-  const uint32_t i = blockIdx.x * WG + threadIdx.x;
-  if (i >= n_total) return;
+  const uint32_t j = blockIdx.x * WG + threadIdx.x;
+  if (j >= n_total) return;
+  const uint64_t i = gidx ? gidx[j] : j;
   Attr a;
   a.rgba = (uint32_t)(splitmix64(key_rgb + 4ull * i) & 0xFFFFFFu);
   float nx = 2.0f * u24(splitmix64(key_nrm + 4ull * i + 0)) - 1.0f;
@@ -107,7 +128,7 @@ __global__ __launch_bounds__(WG) void synth_attr_kernel(uint64_t key_rgb, uint64
   if (len < 1e-12f) { nx = 0.f; ny = 0.f; nz = 1.f; }
   else { nx = nx / len; ny = ny / len; nz = nz / len; }
   a.nx = nx; a.ny = ny; a.nz = nz;
-  attr[i] = a;
+  attr[j] = a;
 }
 
 // reference Point: ver f64x3 @0, normal f64x3 @24, color i32x3 @48, U @64, V @72 (80 B)
@@ -365,21 +386,22 @@ inline dim3 grid_for(uint32_t n) { return dim3((n + WG - 1) / WG); }
 
 template <class T>
 void pt_launch_synth_xyz(uint64_t seed, uint64_t stream, uint32_t n_total, int axis, double lo, double hi, T* x, T* y, T* z, uint32_t* gidx,
-                         uint32_t* counter, uint32_t capacity, int round_f16, int dist, uint64_t src_total, uint64_t tgt_total, hipStream_t s) {
+                         uint32_t* counter, uint32_t capacity, int round_f16, int dist, uint64_t src_total, uint64_t tgt_total, hipStream_t s,
+                         uint32_t* wg_cnt, const uint32_t* wg_off) {
   if (!n_total) return;
   hipLaunchKernelGGL(synth_xyz_kernel<T>, grid_for(n_total), dim3(WG), 0, s, stream_key(seed, stream), n_total, axis, lo, hi, x, y, z, gidx,
-                     counter, capacity, round_f16, dist, seed, (int)stream, src_total, tgt_total);
+                     counter, capacity, round_f16, dist, seed, (int)stream, src_total, tgt_total, wg_cnt, wg_off);
 }
 template void pt_launch_synth_xyz<float>(uint64_t, uint64_t, uint32_t, int, double, double, float*, float*, float*, uint32_t*, uint32_t*, uint32_t,
-                                         int, int, uint64_t, uint64_t, hipStream_t);
+                                         int, int, uint64_t, uint64_t, hipStream_t, uint32_t*, const uint32_t*);
 template void pt_launch_synth_xyz<__half>(uint64_t, uint64_t, uint32_t, int, double, double, __half*, __half*, __half*, uint32_t*, uint32_t*, uint32_t,
-                                          int, int, uint64_t, uint64_t, hipStream_t);
+                                          int, int, uint64_t, uint64_t, hipStream_t, uint32_t*, const uint32_t*);
 template void pt_launch_synth_xyz<double>(uint64_t, uint64_t, uint32_t, int, double, double, double*, double*, double*, uint32_t*, uint32_t*,
-                                          uint32_t, int, int, uint64_t, uint64_t, hipStream_t);
+                                          uint32_t, int, int, uint64_t, uint64_t, hipStream_t, uint32_t*, const uint32_t*);
 
-void pt_launch_synth_attr(uint64_t seed, uint32_t n_total, Attr* attr, hipStream_t s) {
+void pt_launch_synth_attr(uint64_t seed, uint32_t n_total, Attr* attr, hipStream_t s, const uint32_t* gidx) {
   if (!n_total) return;
-  hipLaunchKernelGGL(synth_attr_kernel, grid_for(n_total), dim3(WG), 0, s, stream_key(seed, 2), stream_key(seed, 3), n_total, attr);
+  hipLaunchKernelGGL(synth_attr_kernel, grid_for(n_total), dim3(WG), 0, s, stream_key(seed, 2), stream_key(seed, 3), n_total, attr, gidx);
 }
 void pt_launch_aos_split(const void* aos, uint32_t n, double* x, double* y, double* z, Attr* attr, hipStream_t s) {
   if (!n) return;

@@ -128,10 +128,10 @@ void pt_launch_slab_need(const T* x, const T* y, const T* z, const double* d2, u
 template <class T>
 void pt_launch_synth_xyz(uint64_t seed, uint64_t stream, uint32_t n_total, int axis, double lo, double hi, T* x, T* y, T* z,
                          uint32_t* gidx, uint32_t* counter, uint32_t capacity, int round_f16, int dist, uint64_t src_total,
-                         uint64_t tgt_total, hipStream_t s);
+                         uint64_t tgt_total, hipStream_t s, uint32_t* wg_cnt = nullptr, const uint32_t* wg_off = nullptr);      // wg_cnt / wg_off: slabs in index order (pt_attr.hip)
 void pt_launch_half_to_float(const void* in_half, float* out, uint64_t count, hipStream_t s);
 void pt_launch_float_to_double(const float* in, double* out, uint64_t count, hipStream_t s);
-void pt_launch_synth_attr(uint64_t seed, uint32_t n_total, Attr* attr, hipStream_t s);
+void pt_launch_synth_attr(uint64_t seed, uint32_t n_total, Attr* attr, hipStream_t s, const uint32_t* gidx = nullptr);      // gidx: n_total records, of the points gidx[j]
 // reference AoS records (80-B stride, device copy) -> planar f64 xyz + attribute table
 void pt_launch_aos_split(const void* aos, uint32_t n, double* x, double* y, double* z, Attr* attr, hipStream_t s);
 void pt_launch_pack_attr(const uint8_t* rgb, const float* nrm, uint32_t n, Attr* attr, hipStream_t s);
@@ -173,6 +173,15 @@ void pt_launch_xunpack(const double* rreq, uint32_t r, T* xyz_planar, double* bo
 // merge bucket answers (bi, bd)[cnt][k] into rows[e]'s lists in place; flags[row] = 1 for every row touched
 void pt_launch_xmerge(const uint32_t* rows, uint32_t cnt, const uint32_t* bi, const double* bd, int k, uint32_t* idx, double* d2, uint8_t* flags, hipStream_t s);
 void pt_launch_xflag_rows(const uint8_t* flags, uint32_t m, uint32_t* rows, uint32_t* count, hipStream_t s);
+// slabs with LOCAL ids in their records (ascending gidx) and their own points' attribute records only (pt_exchange.hip)
+void pt_launch_ids_to_global(uint32_t* idx, size_t count, const uint32_t* gidx, hipStream_t s);                       // idx[i] = gidx[idx[i]] (NOIDX stays)
+void pt_launch_ids_to_local(const uint32_t* in, size_t count, const uint32_t* gidx, uint32_t n, uint32_t* out, hipStream_t s);      // binary search; NOIDX for another slab's points
+void pt_launch_xgather_attr(const uint32_t* ids, size_t count, const uint32_t* gidx, uint32_t n, const Attr* attr, Attr* out, hipStream_t s);
+void pt_launch_xmerge_attr(const uint32_t* rows, uint32_t cnt, const uint32_t* bi, const double* bd, const Attr* ba, int k, uint32_t* idx, double* d2, Attr* rattr,
+                           uint8_t* flags, const uint32_t* gidx, uint32_t n, const Attr* attr, hipStream_t s);
+void pt_launch_blend_rows_attr(const uint32_t* rows, const uint32_t* rows_n, uint32_t m_max, const uint32_t* idx, const double* d2, const Attr* rattr, int k, int mode,
+                               float* rgb_out, float* nrm_out, hipStream_t s);
+void pt_launch_ascending(const uint32_t* gidx, uint32_t n, uint32_t* flag, hipStream_t s);                             // *flag |= 1 unless gidx is strictly ascending
 // blend of the listed rows (row ids, not sorted positions) from their idx / d2 lists
 void pt_launch_blend_rows(const uint32_t* rows, const uint32_t* rows_n, uint32_t m_max, const uint32_t* idx, const double* d2, int k, int mode,
                           const Attr* attr, uint32_t n_attr, float* rgb_out, float* nrm_out, hipStream_t s);

@@ -242,24 +242,31 @@ inline int run_rank(const Options& o) {
   std::vector<double> bounds;
   slab_bounds(cloud, world, axis, bounds);
   const double lo = bounds[(size_t)rank], hi = bounds[(size_t)rank + 1];
+  // The slab's points in the order of the file: their global indices ascend, so the records can carry POSITIONS in the slab
+  // (pt_set_param "local_ids") and the attribute table holds this slab's points only -- 16 bytes x (points / ranks) on every GPU
+  // instead of a copy of the whole table; what another slab contributes to a list travels with its record (round 4).
   std::vector<uint32_t> gidx;
   std::vector<double> sx, sy, sz;
+  std::vector<uint8_t> srgb;
+  std::vector<float> snrm;
   for (const Piece& q : cloud.p) {
     const double* ax = axis == 0 ? q.x : (axis == 1 ? q.y : q.z);
     for (uint64_t i = 0; i < q.count; ++i)
-      if (ax[i] >= lo && ax[i] < hi) { gidx.push_back((uint32_t)(q.first + i)); sx.push_back(q.x[i]); sy.push_back(q.y[i]); sz.push_back(q.z[i]); }
+      if (ax[i] >= lo && ax[i] < hi) {
+        gidx.push_back((uint32_t)(q.first + i)); sx.push_back(q.x[i]); sy.push_back(q.y[i]); sz.push_back(q.z[i]);
+        srgb.insert(srgb.end(), q.rgb + 3 * i, q.rgb + 3 * i + 3); snrm.insert(snrm.end(), q.nrm + 3 * i, q.nrm + 3 * i + 3);
+      }
   }
   const size_t ns = gidx.size();
   {
     std::vector<double> sxyz(std::max<size_t>(ns, 1) * 3);
     std::copy(sx.begin(), sx.end(), sxyz.begin()); std::copy(sy.begin(), sy.end(), sxyz.begin() + (long)ns); std::copy(sz.begin(), sz.end(), sxyz.begin() + 2 * (long)ns);
     std::vector<double>().swap(sx); std::vector<double>().swap(sy); std::vector<double>().swap(sz);
+    pt_set_param(ctx, "local_ids", 1.0);
     if (pt_build_soa_indexed(ctx, sxyz.data(), PT_F64, gidx.data(), ns, 0) != PT_OK) return die("build failed");
   }
-  // the attribute table (indexed by global index, replicated on every GPU so that the blend is local) straight from the mapped pieces
-  for (const Piece& q : cloud.p)
-    if (pt_set_attributes_range(ctx, q.first, q.count, q.rgb, q.nrm, cloud.n) != PT_OK) return die("attribute upload failed");
-  if (!cloud.n && pt_set_attributes_range(ctx, 0, 0, nullptr, nullptr, 0) != PT_OK) return die("attribute upload failed");
+  if (pt_set_attributes_local(ctx, srgb.data(), snrm.data(), 0) != PT_OK) return die("attribute upload failed");
+  std::vector<uint8_t>().swap(srgb); std::vector<float>().swap(snrm);
   if (rank == 0) std::cout << "Built Kd tree in: " << since(t_task) << " seconds" << std::endl;
   t_task = clk::now();
   // ---- mesh: the vertices homed in this slab ---------------------------------------------------------------------------------

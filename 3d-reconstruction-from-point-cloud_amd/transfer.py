@@ -139,6 +139,13 @@ class PointsTransfer:
         n = (r if r is not None else m).shape[0]
         self._chk(self._L.pt_set_attributes(self._h, _ptr(r), _ptr(m), n, 0))
 
+    def set_attributes_local(self, rgb, nrm):
+        """The attribute records of THIS slab's points only, in the order of the slab's arrays (after set_param("local_ids", 1) and a
+        build with strictly ascending global indices): 16 n bytes on the GPU instead of 16 N."""
+        r = None if rgb is None else np.ascontiguousarray(rgb, dtype=np.uint8)
+        m = None if nrm is None else np.ascontiguousarray(nrm, dtype=np.float32)
+        self._chk(self._L.pt_set_attributes_local(self._h, _ptr(r), _ptr(m), 0))
+
     def set_attributes_range(self, first, rgb, nrm, n_total):
         """Records [first, first + len) of the attribute table of n_total points, from host arrays (rgb [c,3] u8, nrm [c,3] f32)."""
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8) if rgb is not None else None

@@ -317,6 +317,10 @@ def main():
                     help="N > 1: native = pt_exchange_merge_dev (RCCL behind the C ABI: one count-matrix all-gather, grouped send/recv) -- if its "
                          "communicator does not come up the run FAILS (non-zero exit), it never changes protocol by itself; "
                          "torch = the torch.distributed all-gather protocol of sharding.py (what the gloo CPU tests drive), an explicit choice")
+    ap.add_argument("--attributes", default="sharded", choices=["sharded", "replicated"],
+                    help="N > 1 with the native exchange: sharded = every rank generates its slab in index order, keeps positions in its records "
+                         "and the attribute records of its OWN points only (16 n / N bytes; the answers carry their candidates' records); "
+                         "replicated = every rank holds the whole 16 n-byte table (what --exchange torch always does)")
     ap.add_argument("--source-points", dest="n", type=int, default=0, help="override the workload's source count (rehearsals)")
     ap.add_argument("--target-points", dest="m", type=int, default=0, help="override the workload's target count (rehearsals)")
     ap.add_argument("--dry-run", action="store_true",
@@ -404,6 +408,9 @@ def main():
             sx = torch.empty((3, probe.num_targets), dtype=torch.float32, device=dev)
             probe.resident_target_xyz_dev(sx)
             bounds = sharding.quantile_slab_bounds(sx[axis], world)
+    sharded_attr = native and args.attributes == "sharded"
+    if sharded_attr:
+        pt.set_param("local_ids", 1)
     if world > 1:
         pt.build_synth(n_total, seed, slab_axis=axis, slab_lo=bounds[rank], slab_hi=bounds[rank + 1], **gen)
         pt.targets_synth(m_total, seed, slab_axis=axis, slab_lo=bounds[rank], slab_hi=bounds[rank + 1], **gen)
@@ -531,7 +538,8 @@ def main():
                        "step": "grid build + target binning + k-NN with fused mean blend + slab exchange/merge%s, inputs resident in HBM"
                                % (" + PCA normals" if with_pca else ""),
                        "parallelism": "slab%d" % world if world > 1 else "single", "backend": args.backend if world > 1 else None,
-                       "exchange": ("native RCCL (pt_exchange_merge_dev)" if native else "torch.distributed all-gather (--exchange torch)") if world > 1 else None},
+                       "exchange": ("native RCCL (pt_exchange_merge_dev)" if native else "torch.distributed all-gather (--exchange torch)") if world > 1 else None,
+                       "attributes": ("sharded: 16 n / N bytes per rank" if sharded_attr else "replicated: 16 n bytes per rank") if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(KERNEL_NAMES[dom], args.workload, world),
                          "traffic_source": pmc_file, "alg_bytes_per_launch": alg, "alg_bytes_formula": "SURVEY.md 8(d)",

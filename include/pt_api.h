@@ -141,7 +141,9 @@ int  pt_set_stream(pt_ctx*, void* hip_stream);
  * that hold ONE position more than 32 times keep their 32 lowest indices in front and searches read that front only; 0 = off),
  * "tile_sparse" (the tile kernel over a list of the blocks that hold targets: 0 never, 1 always, 2 = on clouds that leave most of
  * their grid empty, default), "tile_contrast" (1: on clouds with strong density contrast the tile kernel runs first, k <= 24, and the
- * wave kernel takes what it leaves; 0, default: a wave per target -- measured faster). */
+ * wave kernel takes what it leaves; 0, default: a wave per target -- measured faster), "local_ids" (1: the next slab build -- ascending
+ * global indices, or a slab pt_build_synth generates -- keeps positions in its records and its own attribute records only; see
+ * pt_set_attributes_local). */
 int  pt_set_param(pt_ctx*, const char* name, double value);
 const char* pt_last_error(pt_ctx*);
 int  pt_stats(pt_ctx*, pt_stats_t* out);
@@ -154,6 +156,14 @@ int  pt_build_aos(pt_ctx*, const pt_point* cloud, uint64_t n);
  * device memory according to on_device. PT_F16 clouds stay fp16 in the resident input (6 bytes per
  * point) and are widened -- exactly -- as the build reads them; answers are those of the fp32 cloud
  * holding the same values. */
+/* Slabs that keep their OWN points' attribute records only (round 4): after pt_set_param("local_ids", 1), a
+ * pt_build_soa_indexed whose global indices are STRICTLY ASCENDING (PT_ERR_ARG otherwise) sorts each point's position in the slab's
+ * arrays into the records -- positions order like indices, so results are unchanged -- and pt_set_attributes_local uploads the records
+ * of exactly those n points in that order (rgb [n][3], nrm [n][3]): 16 n bytes per GPU instead of 16 N.  Finished neighbour lists carry
+ * global indices as ever.  pt_exchange_merge_* then sends every candidate's record with it and blends the completed rows from what
+ * arrived; every rank of a job must run the same mode.  pt_blend_dev on such a context blends the entries that belong to this slab
+ * (lists the exchange completed are blended by the exchange). */
+int  pt_set_attributes_local(pt_ctx*, const uint8_t* rgb, const float* nrm, int on_device);
 int  pt_build_soa(pt_ctx*, const void* xyz, int xyz_type, const uint8_t* rgb, const float* nrm,
                   uint64_t n, int on_device);
 /* Same, for one spatial slab of a larger cloud: gidx[i] is the point's index in the whole cloud

@@ -35,7 +35,25 @@ torch.cuda.synchronize()
 wi, wd = O.KdTree(src).query(tgt[:, mine], k)
 assert np.array_equal(i_.cpu().numpy().view(np.uint32), wi) and np.array_equal(d_.cpu().numpy(), wd)
 assert st["crossing"] > 0 and st["answered"] > 0
-print("rank %d ok" % rank, st, flush=True)
+# the same job with the attribute table SHARDED: generated slabs in index order, each rank's own records only, the answers carrying theirs
+q = pkg.PointsTransfer(device=rank, k_hint=8)
+uid2 = [q.comm_unique_id() if rank == 0 else None]
+dist.broadcast_object_list(uid2, src=0)
+q.comm_init(world, rank, uid2[0])
+q.set_param("local_ids", 1)
+q.build_synth(n, seed, slab_axis=0, slab_lo=bounds[rank], slab_hi=bounds[rank + 1])
+assert q.num_source == len(sel)
+q.set_targets(np.ascontiguousarray(tgt[:, mine]))
+c_ = torch.empty((len(mine), 3), dtype=torch.float32, device="cuda"); n_ = torch.empty((len(mine), 3), dtype=torch.float32, device="cuda")
+q.query_blend_resident_dev(k, pkg.BLEND_MEAN, i_, d_, c_, n_)
+st2 = q.exchange_merge_dev(x, pkg.F32, len(mine), k, 0, bounds, i_, d_, pkg.BLEND_MEAN, c_, n_)
+torch.cuda.synchronize()
+assert np.array_equal(i_.cpu().numpy().view(np.uint32), wi) and np.array_equal(d_.cpu().numpy(), wd)
+rc, rn = O.blend(wi, wd, O.synth_rgb(seed, n), O.synth_nrm(seed, n), mode=0)
+assert np.abs(c_.cpu().numpy() - rc).max() / 255.0 <= 1e-5 and np.abs(n_.cpu().numpy() - rn).max() <= 1e-5
+assert st2["bytes_sent"] > st["bytes_sent"]                       # 28 bytes per candidate instead of 12
+print("rank %d ok" % rank, st, st2, flush=True)
 dist.barrier()
+q.comm_destroy(); q.close()
 p.comm_destroy(); p.close()
 dist.destroy_process_group()

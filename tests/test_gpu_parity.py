@@ -1358,11 +1358,13 @@ def test_streamed_source_100m_equals_resident(pkg, oracle):
 
 
 # ---- native slab exchange behind the C ABI (pt_exchange_*): same phases as the RCCL path, device copies as transport ------------
-@pytest.mark.parametrize("g,k,f64", [(2, 8, False), (3, 20, True), (5, 8, False)])
-def test_native_exchange_on_logical_slabs(pkg, oracle, g, k, f64):
+@pytest.mark.parametrize("g,k,f64,sharded", [(2, 8, False, False), (3, 20, True, False), (5, 8, False, False), (2, 8, False, True), (3, 20, True, True), (5, 16, False, True)])
+def test_native_exchange_on_logical_slabs(pkg, oracle, g, k, f64, sharded):
     """G contexts of one process, one slab each (equal-count quantiles along x; the last slab may hold NO targets): home search,
     then pt_exchange_merge_local -- count matrix, owner-to-owner requests, bounded answers, merge, re-blend of the completed rows.
-    Result: the global search bit for bit, and the blend of every row within 1e-5 of the oracle's."""
+    Result: the global search bit for bit, and the blend of every row within 1e-5 of the oracle's.
+    sharded (round 4): every slab keeps LOCAL ids in its records ("local_ids": ascending global indices) and the attribute records of its
+    OWN points only (set_attributes_local); the fused home blend gathers from that table, the answers carry their candidates' records."""
     import torch
     n, m, seed = 150000, 9000, 0xE0 + g
     dt = np.float64 if f64 else np.float32
@@ -1380,8 +1382,15 @@ def test_native_exchange_on_logical_slabs(pkg, oracle, g, k, f64):
     for s in range(g):
         p = pkg.PointsTransfer(device=0, k_hint=k)
         sel = np.nonzero((src[0] >= bounds[s]) & (src[0] < bounds[s + 1]))[0]
+        if sharded:
+            p.set_param("local_ids", 1)
         p.build(np.ascontiguousarray(src[:, sel]), gidx=sel.astype(np.uint32))
-        p.set_attributes(rgb, nrm)                                           # the table is replicated: indexed by the global index
+        if sharded:
+            p.set_attributes_local(rgb[sel], nrm[sel])                       # this slab's points only: 1 / g of the table
+            with pytest.raises(pkg.PtError):
+                p.set_attributes(rgb, nrm)
+        else:
+            p.set_attributes(rgb, nrm)                                       # the table is replicated: indexed by the global index
         mine = np.nonzero(home == s)[0]
         ms = len(mine)
         x = torch.from_numpy(np.ascontiguousarray(tgt[:, mine])).cuda()
@@ -1390,6 +1399,9 @@ def test_native_exchange_on_logical_slabs(pkg, oracle, g, k, f64):
         if ms:
             p.query_dev(x, xt, ms, k, i_, d_)
             p.blend_dev(i_, d_, ms, k, pkg.BLEND_MEAN, c_, n_)
+            if sharded:                                                      # the home lists name home points, by GLOBAL index
+                hi = i_.cpu().numpy().view(np.uint32)
+                assert np.isin(hi[hi != pkg.NOIDX], sel).all()
         pts.append(p); xs.append(x); ii.append(i_); dd.append(d_); cc.append(c_); nn.append(n_); rows.append(mine)
     assert g != 5 or len(rows[-1]) == 0
     pkg.PointsTransfer.exchange_merge_local(pts, xs, xt, k, 0, bounds, ii, dd, pkg.BLEND_MEAN, cc, nn)
@@ -1399,6 +1411,99 @@ def test_native_exchange_on_logical_slabs(pkg, oracle, g, k, f64):
         gi[rows[s]] = ii[s].cpu().numpy().view(np.uint32); gd[rows[s]] = dd[s].cpu().numpy()
         gc[rows[s]] = cc[s].cpu().numpy(); gn[rows[s]] = nn[s].cpu().numpy()
     _check_exact((gi, gd), (want_i, want_d), "native exchange g=%d" % g)
+    rc, rn = oracle.blend(want_i, want_d, rgb, nrm, mode=0)
+    assert np.abs(gc - rc).max() / 255.0 <= TOL and np.abs(gn - rn).max() <= TOL
+    for p in pts:
+        p.close()
+
+
+def test_local_id_slab_matches_the_global_id_slab(pkg, oracle):
+    """A slab whose records carry positions instead of global indices ("local_ids"): the same lists -- ties among duplicates resolved by the
+    global index, which ascending indices make the positional order -- the fused blend from the slab's own attribute records within 1e-5 of
+    the replicated table's, on the tile kernel and on the wave kernel; indices that do not ascend are refused."""
+    import torch
+    rng = np.random.default_rng(55)
+    n_all, n, m, k = 300_000, 120_000, 5000, 16
+    src_all = rng.random((3, n_all), dtype=np.float32)
+    src_all[:, 0:294000:7] = src_all[:, 3:294000:7]                           # exact duplicates: ties decided by the index
+    sel = np.sort(rng.choice(n_all, n, replace=False)).astype(np.uint32)
+    src = np.ascontiguousarray(src_all[:, sel])
+    tgt = rng.random((3, m), dtype=np.float32)
+    tgt[:, :500] = src[:, rng.integers(0, n, 500)]
+    rgb, nrm = oracle.synth_rgb(9, n_all), oracle.synth_nrm(9, n_all)
+    wi, wd = oracle.knn_bruteforce(src, tgt, k, gidx=sel)
+    rc, rn = oracle.blend(wi, wd, rgb, nrm, mode=1)
+    for tile in (1, 0):
+        with pkg.PointsTransfer(device=0, k_hint=k) as p:
+            p.set_param("local_ids", 1); p.set_param("tile", tile)
+            if tile == 0:
+                p.set_param("wave_force", 1)
+            p.build(src, gidx=sel)
+            p.set_attributes_local(rgb[sel], nrm[sel])
+            p.set_targets(tgt)
+            idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
+            c_ = torch.empty((m, 3), dtype=torch.float32, device="cuda"); n_ = torch.empty((m, 3), dtype=torch.float32, device="cuda")
+            p.query_blend_resident_dev(k, pkg.BLEND_INV_D2, idx, d2, c_, n_)
+            torch.cuda.synchronize()
+            _check_exact((idx.cpu().numpy().view(np.uint32), d2.cpu().numpy()), (wi, wd), "local ids, tile=%d" % tile)
+            assert np.abs(c_.cpu().numpy() - rc).max() / 255.0 <= TOL and np.abs(n_.cpu().numpy() - rn).max() <= TOL
+            c2 = torch.empty_like(c_); n2 = torch.empty_like(n_)
+            p.blend_dev(idx, d2, m, k, pkg.BLEND_INV_D2, c2, n2)              # a finished list (global indices) against the local table
+            torch.cuda.synchronize()
+            assert np.abs(c2.cpu().numpy() - rc).max() / 255.0 <= TOL and np.abs(n2.cpu().numpy() - rn).max() <= TOL
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:
+        p.set_param("local_ids", 1)
+        bad = sel.copy(); bad[[10, 11]] = bad[[11, 10]]
+        with pytest.raises(pkg.PtError):
+            p.build(src, gidx=bad)
+
+
+@pytest.mark.parametrize("clustered", [False, True])
+def test_generated_slabs_in_index_order_carry_their_own_attributes(pkg, oracle, clustered):
+    """bench.py --gpus N as round 4 builds it: every rank GENERATES its slab in index order ("local_ids" before build_synth: per-workgroup
+    counts, a scan, ranked writes), so its records carry positions and its attribute table holds its own n / G records; the native exchange
+    (answers carrying their candidates' records) then gives the global search bit for bit and the oracle's blend within 1e-5."""
+    import torch
+    g, n, m, k, seed = 3, 200_000, 6000, 8, 0xA7
+    dist = 1 if clustered else 0
+    xt = pkg.F16 if clustered else pkg.F32
+    src = oracle.synth_xyz(seed, 0, n, dist=dist, n_total=n, m_total=m); tgt = oracle.synth_xyz(seed, 1, m, dist=dist, n_total=n, m_total=m)
+    if clustered:
+        src = src.astype(np.float16).astype(np.float32)
+    rgb, nrm = oracle.synth_rgb(seed, n), oracle.synth_nrm(seed, n)
+    want_i, want_d = oracle.KdTree(src.astype(np.float64)).query(tgt.astype(np.float64), k)
+    bounds = [-math.inf] + [float(v) for v in np.quantile(src[0], np.arange(1, g) / g)] + [math.inf]
+    home = np.clip(np.searchsorted(np.array(bounds), tgt[0], side="right") - 1, 0, g - 1)
+    pts, xs, ii, dd, cc, nn, rows = [], [], [], [], [], [], []
+    for s in range(g):
+        p = pkg.PointsTransfer(device=0, k_hint=k)
+        p.set_param("local_ids", 1)
+        p.build_synth(n, seed, xyz_type=xt, dist=dist, slab_axis=0, slab_lo=bounds[s], slab_hi=bounds[s + 1])
+        sel = np.nonzero((src[0] >= bounds[s]) & (src[0] < bounds[s + 1]))[0]
+        assert p.num_source == len(sel)
+        with pytest.raises(pkg.PtError):
+            p.set_attributes(rgb, nrm)                                       # the table is the slab's own now
+        mine = np.nonzero(home == s)[0]
+        ms = len(mine)
+        x = torch.from_numpy(np.ascontiguousarray(tgt[:, mine])).cuda()
+        i_ = torch.empty((ms, k), dtype=torch.int32, device="cuda"); d_ = torch.empty((ms, k), dtype=torch.float64, device="cuda")
+        c_ = torch.zeros((ms, 3), dtype=torch.float32, device="cuda"); n_ = torch.zeros((ms, 3), dtype=torch.float32, device="cuda")
+        p.set_targets(np.ascontiguousarray(tgt[:, mine]))
+        p.query_blend_resident_dev(k, pkg.BLEND_MEAN, i_, d_, c_, n_)        # the fused home blend, from the local table
+        torch.cuda.synchronize()
+        hi = i_.cpu().numpy().view(np.uint32)
+        assert np.isin(hi[hi != pkg.NOIDX], sel).all()                       # global indices, of home points
+        sub_i, sub_d = oracle.knn_bruteforce(src[:, sel], tgt[:, mine[:200]], k, gidx=sel.astype(np.uint32))
+        assert np.array_equal(hi[:200], sub_i) and np.array_equal(d_.cpu().numpy()[:200], sub_d)
+        pts.append(p); xs.append(x); ii.append(i_); dd.append(d_); cc.append(c_); nn.append(n_); rows.append(mine)
+    assert sum(p.num_source for p in pts) == n
+    pkg.PointsTransfer.exchange_merge_local(pts, xs, pkg.F32, k, 0, bounds, ii, dd, pkg.BLEND_MEAN, cc, nn)
+    torch.cuda.synchronize()
+    gi = np.empty((m, k), np.uint32); gd = np.empty((m, k)); gc = np.empty((m, 3), np.float32); gn = np.empty((m, 3), np.float32)
+    for s in range(g):
+        gi[rows[s]] = ii[s].cpu().numpy().view(np.uint32); gd[rows[s]] = dd[s].cpu().numpy()
+        gc[rows[s]] = cc[s].cpu().numpy(); gn[rows[s]] = nn[s].cpu().numpy()
+    _check_exact((gi, gd), (want_i, want_d), "generated local-id slabs")
     rc, rn = oracle.blend(want_i, want_d, rgb, nrm, mode=0)
     assert np.abs(gc - rc).max() / 255.0 <= TOL and np.abs(gn - rn).max() <= TOL
     for p in pts:
