@@ -17,7 +17,10 @@ with pkg.PointsTransfer(device=0, k_hint=k) as p:
     p.build_synth(n, seed, **gen); p.targets_synth(m, seed, **gen)
     idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((m, k), dtype=torch.float64, device="cuda")
     rgb = torch.empty((m, 3), dtype=torch.float32, device="cuda"); nrm = torch.empty((m, 3), dtype=torch.float32, device="cuda")
+    pn = torch.empty((m, 3), dtype=torch.float32, device="cuda") if name == "C3" else None
     for it in range(steps):
         p.rebuild(); p.query_blend_resident_dev(k, pkg.BLEND_MEAN, idx, d2, rgb, nrm)
+        if pn is not None:
+            p.pca_normals_dev(idx, m, k, pn)          # (bench.py's C3 step ends with the PCA normals)
     torch.cuda.synchronize()
     st = p.stats(); print(name, [round(v, 3) for v in st["ms_kernel"]], "leftover", st["n_leftover"])
