@@ -40,7 +40,7 @@ class Stats(C.Structure):
         ("n_refine", C.c_int32), ("bbox_guess", C.c_int32), ("ms_bake", C.c_double),
         ("n_nodes", C.c_uint32), ("refine_levels", C.c_int32), ("max_cell_points", C.c_uint32), ("n_wave", C.c_uint32),
         ("pass1_pooled", C.c_int32), ("stream_skipped", C.c_int32), ("stream_revisited", C.c_int32), ("pass2_pooled", C.c_int32),
-        ("uniform_probe", C.c_int32), ("dup_leaves", C.c_int32),
+        ("uniform_probe", C.c_int32), ("dup_leaves", C.c_int32), ("presort_refine", C.c_int32), ("n_sorts", C.c_int32), ("ordered_input", C.c_int32),
     ]
 
 

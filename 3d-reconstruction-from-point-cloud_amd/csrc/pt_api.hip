@@ -74,6 +74,7 @@ struct pt_ctx {
   bool pool2_ok = true, pool2 = true, uniform_seen = false;   // pass 2 without its histogram: allowed ("pool2"), not failed yet on this cloud, and the last build of
                                // this resident cloud found it uniform (reset by an upload together with pool_ok)
   bool pool_ok = true;         // big clouds, two-level sorts: pass 1 without its histogram pass (cleared when a bin outgrew its sampled region; reset by an upload)
+  int presort_refine = 1;                 // first builds of big non-uniform clouds refine the cell size from the sample, before the first sort ("presort_refine")
   uint64_t pool_min_points = 32u << 20;   // ... from this size up ("pool_min_points"; 0 switches the pooled pass 1 off)
   int n_cu = 256;              // compute units of the device: persistent workgroups of the pooled pass 1
   GridParams gp{};
@@ -345,6 +346,9 @@ int rebuild(pt_ctx* c) {
   uint32_t max_cell = 0;            // points of the fullest cell of the final grid (adaptive builds)
   bool pool_failed = false;         // the pooled pass 1 overflowed a region and the build was redone with the exact pass 1
   bool pool2_failed = false;        // the same for the pooled pass 2
+  int presort_iters = 0, nsorts = 0;   // refinements of the cell size taken from the sample, before any sort; sorts run by this build
+  bool presort_unverified = false;     // ... and no sort has counted the occupied cells of the refined grid yet
+  c->st.presort_refine = 0; c->st.n_sorts = 0; c->st.ordered_input = 0;
   for (int iter = 0;; ++iter) {
     choose_grid(c, mn, mx, force_h);
     int pad_cells[3] = {0, 0, 0};         // empty cells around the cloud on every side (a grid laid out from a sampled box)
@@ -375,7 +379,12 @@ int rebuild(pt_ctx* c) {
     // histogram too: block regions from the macro counts (pt_grid.hip, pool2_sizes_kernel); the pass-2 output then carries slack.
     // A cloud nothing is known about yet (its FIRST build) is asked through a 1/64 sample, one short read-back (round 4: a detail-transfer
     // run builds its index once -- reference src/pointsTransfer.cpp:259 -- so the first build is the one that counts)
-    if (!c->uniform_known && iter == 0 && force_h == 0.0 && c->pool2_ok && c->pool2 && c->adaptive && c->pool_min_points && c->n >= c->pool_min_points &&
+    // The same sample also bounds the points per occupied cell from below (pt_grid.hip, uniform_check_kernel): when that bound already says
+    // what the occupancy count after the sort would say -- far more than rho points per occupied cell: a surface, clusters -- the cell size
+    // is refined BEFORE the first sort, by the rule the occupancy count is held to below, and the sample is asked again on the finer grid
+    // (at most three times: a fraction of a millisecond each instead of a sort each; "presort_refine").  The sort's own count still decides.
+    const bool presort_again = presort_iters > 0 && presort_iters < 3 && iter == 0 && nsorts == 0;
+    if (((!c->uniform_known && force_h == 0.0) || presort_again) && iter == 0 && c->pool2_ok && c->pool2 && c->adaptive && c->pool_min_points && c->n >= c->pool_min_points &&
         nblocks > PT_MAXBINS && !pt_sort_group_shift(nblocks)) {
       int olo[3], ohi[3];
       for (int a = 0; a < 3; ++a) { olo[a] = pad_cells[a]; ohi[a] = c->gp.dim[a] - pad_cells[a]; }
@@ -385,12 +394,46 @@ int rebuild(pt_ctx* c) {
       else if (c->src_type == PT_F32) { const float* x = (const float*)c->in_xyz.p; pt_launch_uniform_probe<float>(c->gp, x, x + c->n, x + 2 * c->n, (uint32_t)c->n, olo, ohi, scratch, pflag, c->stream); }
       else { const double* x = (const double*)c->in_xyz.p; pt_launch_uniform_probe<double>(c->gp, x, x + c->n, x + 2 * c->n, (uint32_t)c->n, olo, ohi, scratch, pflag, c->stream); }
       HIPCHK(c, hipMemcpyAsync(c->h_counter + 11, pflag, 4, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(c->h_bbox + 6, scratch + pt_uniform_probe_acc_offset(nblocks), 16, hipMemcpyDeviceToHost, c->stream));     // (h_bbox: 8 pinned 64-bit words, 6 of them the box)
+      HIPCHK(c, hipMemcpyAsync(c->h_bbox + 6, scratch + pt_uniform_probe_acc_offset(nblocks), 32, hipMemcpyDeviceToHost, c->stream));     // (h_bbox: 10 pinned 64-bit words, 6 of them the box)
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      const double chi2 = (double)c->h_bbox[6] / 1024.0, dof = (double)c->h_bbox[7];
-      c->uniform_seen = c->h_counter[11] == 0 && dof > 0.0 && chi2 <= dof + 6.0 * std::sqrt(2.0 * dof) + 16.0;
-      c->uniform_known = true;
-      c->st.uniform_probe = c->uniform_seen ? 1 : -1;
+      if (!presort_again) {
+        const double chi2 = (double)c->h_bbox[6] / 1024.0, dof = (double)c->h_bbox[7];
+        c->uniform_seen = c->h_counter[11] == 0 && dof > 0.0 && chi2 <= dof + 6.0 * std::sqrt(2.0 * dof) + 16.0;
+        c->uniform_known = true;
+        c->st.uniform_probe = c->uniform_seen ? 1 : -1;
+      }
+      // A cloud stored in SPATIAL order (scan lines, tiles, a previous sort) shows a sample of consecutive points a few crowded blocks and nothing
+      // in between: neither the regions of the pooled passes nor the occupancy estimate below can be taken from it.  It gives itself away -- of 64
+      // consecutive points most fall into ONE block -- and the build takes the exact passes and the sort's own count (one sort saved: the pooled
+      // pass 1 would have overflowed and been redone).
+      if (!presort_again) {
+        const uint32_t stride = std::max<uint32_t>(16u, std::min<uint32_t>(256u, (uint32_t)c->n >> 22));
+        const double sampled = (double)c->n / stride;
+        c->st.ordered_input = (double)c->h_bbox[9] > 0.25 * sampled ? 1 : 0;
+        if (c->st.ordered_input) { c->pool_ok = false; c->pool2_ok = false; c->uniform_seen = false; c->st.uniform_probe = -1; pool_records = 0; }
+      }
+      const double occ_ub = (double)c->h_bbox[8] / 16.0;
+      const double rho_lb = occ_ub > 0.0 ? (double)c->n / occ_ub : 0.0;
+      if (getenv("PT_DEBUG_PRESORT")) fprintf(stderr, "presort probe: grid %d %d %d h %.6g occ_ub %.0f rho_lb %.2f iters %d uniform %d\n", c->gp.dim[0], c->gp.dim[1], c->gp.dim[2], c->gp.h, occ_ub, rho_lb, presort_iters, (int)c->uniform_seen);
+      if (c->presort_refine && !c->uniform_seen && !c->st.ordered_input && presort_iters < 3 && rho_lb > 1.5 * c->rho) {
+        const double h_old = c->gp.h;
+        const int d0 = c->gp.dim[0], d1 = c->gp.dim[1], d2 = c->gp.dim[2];
+        const double h_new = h_old * std::pow(c->rho * 1.25 / rho_lb, 1.0 / 2.2);
+        const GridParams keep = c->gp;
+        choose_grid(c, mn, mx, h_new);
+        const bool changed = c->gp.dim[0] != d0 || c->gp.dim[1] != d1 || c->gp.dim[2] != d2;
+        const bool finer = c->gp.h < h_old * 0.95;
+        c->gp = keep;
+        if (changed && finer) {                    // as a refinement after a sort would: the same grid logic, restarted on the finer cell size
+          force_h = h_new;
+          ++presort_iters; ++c->st.n_refine;
+          c->st.presort_refine = presort_iters;
+          presort_unverified = true;
+          --iter;
+          continue;
+        }
+      }
+      presort_iters = presort_iters ? 3 : 0;       // (asked for the last time)
     }
     uint64_t pool2_records = 0;
     if (c->pool2_ok && c->pool2 && c->uniform_seen && nblocks > PT_MAXBINS && !pt_sort_group_shift(nblocks) && c->n)
@@ -412,6 +455,7 @@ int rebuild(pt_ctx* c) {
     const bool verify = guessed && iter == 0;
     if (verify) pt_launch_bbox_init((uint64_t*)c->bbox6.p, c->stream);
     uint64_t* bv = verify ? (uint64_t*)c->bbox6.p : nullptr;
+    ++nsorts; c->st.n_sorts = nsorts;
     { const int r = c->in_half ? run_source_sort<__half, RecF>(c, bv) : (c->src_type == PT_F32 ? run_source_sort<float, RecF>(c, bv) : run_source_sort<double, RecD>(c, bv)); if (r != PT_OK) return r; }
     c->h_counter[15] = 0;
     // ONE read-back per sort (round 4; there were up to three, each a drained pipeline -- a third of a 10 M-point rebuild): the pooled
@@ -441,6 +485,7 @@ int rebuild(pt_ctx* c) {
         guessed = false;
         force_h = 0.0;
         if (c->st.uniform_probe) { c->uniform_known = false; c->uniform_seen = false; }      // (the sample was binned on the wrong grid: asked again on the exact one)
+        presort_iters = 0; presort_unverified = false; c->st.n_refine = 0; c->st.presort_refine = 0;
         if (c->h_counter[15] & 1u) c->pool_ok = false;
         if (c->h_counter[15] & 2u) c->pool2_ok = false;
         --iter;
@@ -459,6 +504,18 @@ int rebuild(pt_ctx* c) {
     const double occupied = std::max<double>(1.0, c->h_counter[8]);
     max_cell = c->h_counter[9];
     c->st.rho_occupied = (double)c->n / occupied;
+    if (presort_unverified) {
+      // The sample's bound holds for points in random order.  A cloud stored in SPATIAL order shows the sample (runs of consecutive points) a few
+      // crowded blocks and nothing in between: the bound then asks for cells far too small.  The count says so -- and the grid is laid out
+      // again from the box alone, this time with the sort's own count as the only judge (what every build did before round 4).
+      presort_unverified = false;
+      if (c->st.rho_occupied < 0.4 * c->rho) {
+        c->st.presort_refine = -presort_iters;
+        presort_iters = 3; force_h = 0.0; c->st.n_refine = 0; iter = -1;
+        c->pool_ok = false; c->pool2_ok = false;          // (a sample that misjudged the occupancy misjudges the regions too)
+        continue;
+      }
+    }
     if (hinted) {
       if (c->st.rho_occupied <= 1.25 * c->hint_rho_occ) { c->st.n_refine = c->hint_refines; break; }     // the grid the last build settled on still fits
       hinted = false; c->hint_h = 0.0; force_h = 0.0; c->st.n_refine = 0; iter = -1;                      // it does not (the resident cloud was changed under us): search again
@@ -907,7 +964,7 @@ int pt_ctx_create(pt_ctx** out, const int* device_ids, int n_devices) {
     if (hipEventCreate(&e) != hipSuccess) { delete c; return PT_ERR_HIP; }
   for (auto& e : c->xev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return PT_ERR_HIP; }
-  if (hipHostMalloc((void**)&c->h_bbox, 8 * sizeof(uint64_t)) != hipSuccess || hipHostMalloc((void**)&c->h_counter, 64) != hipSuccess) {
+  if (hipHostMalloc((void**)&c->h_bbox, 10 * sizeof(uint64_t)) != hipSuccess || hipHostMalloc((void**)&c->h_counter, 64) != hipSuccess) {
     delete c;
     return PT_ERR_HIP;
   }
@@ -974,6 +1031,7 @@ int pt_set_param(pt_ctx* c, const char* name, double value) {
   // "forget": the next build of the resident cloud decides everything a FIRST build decides (sampled bounding box, pooled passes, uniformity
   // sample, cell size) -- what bench.py times as its cold step, buffers already allocated
   if (!strcmp(name, "forget")) { if (value != 0) { c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; } return PT_OK; }
+  if (!strcmp(name, "presort_refine")) { c->presort_refine = value != 0; return PT_OK; }
   if (!strcmp(name, "pool_min_points")) { c->pool_min_points = value < 0 ? 0 : (uint64_t)value; c->pool_ok = true; return PT_OK; }   // pooled pass 1 from this size up (0: never)
   if (!strcmp(name, "guess_min_points")) { c->guess_min_points = value < 1 ? 1 : (uint64_t)value; return PT_OK; }   // sampled-bbox builds from this size up   // 0 group kernel only, 1 auto, 2 small tiles, 3 large tiles
   if (!strcmp(name, "own_stream")) { if (value != 0) c->stream = c->own_stream; return PT_OK; }

@@ -831,12 +831,20 @@ __global__ __launch_bounds__(WG) void pool2_counts_kernel(const uint32_t* __rest
 // shows 32 +- 5.7 sample points); surfaces, clusters and anything with structure below the macro scale do not, by orders of magnitude.
 // The answer only CHOOSES the pass 2: the pooled one still verifies itself (flag bit 2) and is redone exactly if a block outgrows its region.
 template <class Loader>
-__global__ __launch_bounds__(WG) void uniform_probe_kernel(Loader in, GridParams gp, uint32_t n, uint32_t stride, uint32_t* __restrict__ blk_cnt) {
+__global__ __launch_bounds__(WG) void uniform_probe_kernel(Loader in, GridParams gp, uint32_t n, uint32_t stride, uint32_t* __restrict__ blk_cnt,
+                                                           uint32_t* __restrict__ cell_bits, unsigned long long* __restrict__ acc) {
   const uint64_t span = (uint64_t)stride * POOL_SAMPLE_RUN;
+  uint32_t same = 0;         // lanes whose point fell into the block of the wave's first point: consecutive points of a cloud in RANDOM order almost never do
   for (uint64_t i = (uint64_t)blockIdx.x * span + threadIdx.x; i < n; i += (uint64_t)gridDim.x * span) {
-    const uint32_t blk = block_of_rec(gp, in.load((uint32_t)i));
+    int cx, cy, cz;
+    pt_cell_of(gp, in.load((uint32_t)i), cx, cy, cz);
+    const uint32_t blk = pt_block_id(gp.mdim, cx, cy, cz);
+    same += (uint32_t)__popcll(__ballot(blk == (uint32_t)__builtin_amdgcn_readfirstlane((int)blk))) - 1u;
     atomicAdd(&blk_cnt[blk], 1u);                       // (n / 64 atomics over nblocks addresses: ~30 per address)
+    const uint32_t cib = (uint32_t)((cx & 7) | ((cy & 7) << 3) | ((cz & 7) << 6));
+    atomicOr(&cell_bits[(size_t)blk * 16 + (cib >> 5)], 1u << (cib & 31u));      // which of the block's 512 cells the sample has seen
   }
+  if ((threadIdx.x & 63) == 0 && same) atomicAdd(&acc[3], (unsigned long long)same);   // (every lane of a wave counted the same ballots)
 }
 // the macro blocks' sample counts = sums of their 512 blocks' (one atomic per sample point on <= 1024 addresses cost 4 ms at 1e9 points)
 __global__ __launch_bounds__(WG) void uniform_macro_kernel(const uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ macro_cnt) {
@@ -850,10 +858,15 @@ __global__ __launch_bounds__(WG) void uniform_macro_kernel(const uint32_t* __res
 // than e + 6 sqrt(e) + 8 sample points is a clump -- and the block's term (s - e)^2 / e of a CHI-SQUARE sum over all blocks with e >= 4,
 // which is what sees smooth density gradients (a +-15 % drift across a macro block, enough to overflow the regions' 6-sigma slack, moves
 // a 32-point sample count by less than one sigma per block but the sum by tens of sigmas).  acc[0] += term * 1024 (fixed point), acc[1] += 1.
+// Third sum (acc[2], x 16): an estimate of how many CELLS the cloud occupies.  A block's s sample points were seen in u distinct cells: points
+// spread evenly over a of the block's cells show a (1 - exp(-s / a)) of them, which gives a (u = s, every sample point in a cell of its own,
+// says nothing: a = all of the block's cells, the cautious end); the m = stride x s points the block really holds then occupy
+// a (1 - exp(-m / a)) cells.  n over the sum estimates the points per occupied cell the sort would count, which is what the choice of the cell
+// size goes by (pt_api.hip, rebuild) -- from below wherever the sample is thin, so that a refinement it suggests is one the count would ask for.
 __global__ __launch_bounds__(WG) void uniform_check_kernel(GridParams gp, OccBox ob, const uint32_t* __restrict__ macro_cnt, const uint32_t* __restrict__ blk_cnt,
-                                                           uint32_t nblocks, uint32_t* flag, unsigned long long* acc) {
+                                                           const uint32_t* __restrict__ cell_bits, uint32_t nblocks, uint32_t stride, uint32_t* flag, unsigned long long* acc) {
   const uint32_t b = blockIdx.x * WG + threadIdx.x;
-  float term = 0.f;
+  float term = 0.f, occ = 0.f;
   uint32_t used = 0;
   if (b < nblocks) {
   const uint32_t macro = b >> 9, m9 = b & 511u;
@@ -868,12 +881,29 @@ __global__ __launch_bounds__(WG) void uniform_check_kernel(GridParams gp, OccBox
   const double sb = (double)blk_cnt[b];
   if (sb > e + 6.0 * sqrt(e) + 8.0) atomicOr(flag, 1u);
   if (e >= 4.0) { term = (float)((sb - e) * (sb - e) / e); used = 1; }
+  if (sb > 0.0 && cov_b > 0.0) {
+    uint32_t u = 0;
+    const uint4* bits = reinterpret_cast<const uint4*>(cell_bits + (size_t)b * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const uint4 w = bits[i]; u += __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w); }
+    float a = (float)cov_b;
+    const float fs = (float)sb, fu = (float)u;
+    if (fu < fs && a * (1.f - __expf(-fs / a)) > fu) {      // fewer distinct cells than an even spread over the whole block would show: solve for a
+      float lo = fu, hi = a;
+      for (int it = 0; it < 14; ++it) { const float mid = 0.5f * (lo + hi); if (mid * (1.f - __expf(-fs / mid)) < fu) lo = mid; else hi = mid; }
+      a = hi;
+    }
+    occ = a * (1.f - __expf(-(float)stride * fs / a));
+  }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { term += __shfl_xor(term, o); used += __shfl_xor(used, o); }
-  if ((threadIdx.x & 63) == 0 && used) {
-    atomicAdd(&acc[0], (unsigned long long)(term * 1024.0f + 0.5f));
-    atomicAdd(&acc[1], (unsigned long long)used);
+  for (int o = 32; o > 0; o >>= 1) { term += __shfl_xor(term, o); used += __shfl_xor(used, o); occ += __shfl_xor(occ, o); }
+  if ((threadIdx.x & 63) == 0) {
+    if (used) {
+      atomicAdd(&acc[0], (unsigned long long)(term * 1024.0f + 0.5f));
+      atomicAdd(&acc[1], (unsigned long long)used);
+    }
+    if (occ > 0.f) atomicAdd(&acc[2], (unsigned long long)(occ * 16.0f + 0.5f));
   }
 }
 
@@ -1336,7 +1366,8 @@ void pt_launch_uniform_probe(const GridParams& gp, const T* x, const T* y, const
   uint32_t* blk_cnt = scratch;
   uint32_t* macro_cnt = scratch + nblocks;
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(scratch + pt_uniform_probe_acc_offset(nblocks));
-  (void)hipMemsetAsync(scratch, 0, sizeof(uint32_t) * ((size_t)pt_uniform_probe_acc_offset(nblocks) + 4), s);
+  uint32_t* cell_bits = scratch + pt_uniform_probe_acc_offset(nblocks) + 8;      // 16 words per block, 16-byte aligned (the offset is a multiple of four words, the scratch an allocation of its own)
+  (void)hipMemsetAsync(scratch, 0, sizeof(uint32_t) * ((size_t)pt_uniform_probe_acc_offset(nblocks) + 8 + (size_t)nblocks * 16), s);
   (void)hipMemsetAsync(flag, 0, sizeof(uint32_t), s);
   if (!n) return;
   PlanarLoader<T> pl{x, y, z, nullptr};
@@ -1345,12 +1376,12 @@ void pt_launch_uniform_probe(const GridParams& gp, const T* x, const T* y, const
   const uint32_t stride = std::max<uint32_t>(16u, std::min<uint32_t>(256u, n >> 22));
   const uint64_t runs = ((uint64_t)n + POOL_SAMPLE_RUN - 1) / POOL_SAMPLE_RUN;
   const uint32_t gs = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((runs + stride - 1) / stride, 1), 4096);
-  hipLaunchKernelGGL((uniform_probe_kernel<PlanarLoader<T>>), dim3(gs), dim3(WG), 0, s, pl, gp, n, stride, blk_cnt);
+  hipLaunchKernelGGL((uniform_probe_kernel<PlanarLoader<T>>), dim3(gs), dim3(WG), 0, s, pl, gp, n, stride, blk_cnt, cell_bits, acc);
   static_assert(PT_MACRO_BLOCKS == 2 * WG, "two blocks per thread in the macro sums");
   hipLaunchKernelGGL(uniform_macro_kernel, dim3(nmacro), dim3(WG), 0, s, blk_cnt, macro_cnt);
   OccBox ob;
   for (int a = 0; a < 3; ++a) { ob.lo[a] = occ_lo[a]; ob.hi[a] = occ_hi[a]; }
-  hipLaunchKernelGGL(uniform_check_kernel, dim3((nblocks + WG - 1) / WG), dim3(WG), 0, s, gp, ob, macro_cnt, blk_cnt, nblocks, flag, acc);
+  hipLaunchKernelGGL(uniform_check_kernel, dim3((nblocks + WG - 1) / WG), dim3(WG), 0, s, gp, ob, macro_cnt, blk_cnt, cell_bits, nblocks, stride, flag, acc);
 }
 template void pt_launch_uniform_probe<float>(const GridParams&, const float*, const float*, const float*, uint32_t, const int*, const int*, uint32_t*, uint32_t*, hipStream_t);
 template void pt_launch_uniform_probe<__half>(const GridParams&, const __half*, const __half*, const __half*, uint32_t, const int*, const int*, uint32_t*, uint32_t*, hipStream_t);

@@ -56,9 +56,11 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
                                Rec* out_final, Rec* tmp, uint32_t* cell_start, const SortTables& tb, bool do_finalize, hipStream_t s,
                                uint64_t* bbox6_verify = nullptr);   // two-level sorts: pass 1's histogram also reduces the exact bbox into it
 // does a 1/64 sample of the cloud sit in the grid's blocks the way a uniform cloud would (pooled pass 2 on the FIRST build)?  scratch:
-// pt_uniform_probe_acc_offset(nblocks) + 4 words; *flag (device) = 1 when some block holds far more sample points than its macro block's
-// count predicts; the two 64-bit words at scratch + offset: chi-square sum over the blocks (x 1024, fixed point) and how many blocks it is over
-inline uint32_t pt_uniform_probe_acc_offset(uint32_t nblocks) { return (nblocks + nblocks / PT_MACRO_BLOCKS + 2u) & ~1u; }
+// pt_uniform_probe_acc_offset(nblocks) + 8 + 16 nblocks words (the last part: one bit per cell the sample has seen); *flag (device) = 1 when some block holds far more sample points than its macro block's
+// count predicts; the three 64-bit words at scratch + offset: chi-square sum over the blocks (x 1024, fixed point), how many blocks it is over,
+// an estimate of the number of cells the cloud occupies on this grid (x 16), and how many sample points fell into the block of their wave's
+// first point (64 consecutive points: a cloud stored in spatial order gives itself away)
+inline uint32_t pt_uniform_probe_acc_offset(uint32_t nblocks) { return (nblocks + nblocks / PT_MACRO_BLOCKS + 4u) & ~3u; }      // (a multiple of four words: 16-byte reads of what follows)
 template <class T>
 void pt_launch_uniform_probe(const GridParams& gp, const T* x, const T* y, const T* z, uint32_t n, const int occ_lo[3], const int occ_hi[3],
                              uint32_t* scratch, uint32_t* flag, hipStream_t s);

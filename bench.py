@@ -483,7 +483,7 @@ def main():
     st_q = pt.stats()
     first = {"first_build_ms": st_first["ms_build"], "first_build_kernels_ms": [round(v, 4) for v in st_first["ms_kernel"][:6]],
              "first_query_ms": st_q["ms_sort_targets"] + st_q["ms_query"], "first_query_wall_ms": first_query_wall,
-             "first_build_flags": {f: st_first[f] for f in ("pass1_pooled", "pass2_pooled", "uniform_probe", "bbox_guess", "n_refine")}}
+             "first_build_flags": {f: st_first[f] for f in ("pass1_pooled", "pass2_pooled", "uniform_probe", "bbox_guess", "n_refine", "presort_refine", "n_sorts")}}
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -514,7 +514,7 @@ def main():
             torch.cuda.synchronize(); cs.append((time.perf_counter() - tc) * 1e3)
             stc = pt.stats(); cb.append(stc["ms_build"])
         cold = dict(first, cold_step_ms=round(sum(cs) / len(cs), 4), cold_build_ms=round(sum(cb) / len(cb), 4),
-                    cold_flags={f: stc[f] for f in ("pass1_pooled", "pass2_pooled", "uniform_probe", "bbox_guess")},
+                    cold_flags={f: stc[f] for f in ("pass1_pooled", "pass2_pooled", "uniform_probe", "bbox_guess", "n_refine", "presort_refine", "n_sorts")},
                     note="cold_step = forget + rebuild + query on allocated buffers (wall, mean of 3); first_build_ms includes every hipMalloc of the first build")
 
     if rank == 0:

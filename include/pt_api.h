@@ -103,6 +103,13 @@ typedef struct pt_stats_t {
                              * not, 0 not asked (small cloud, one- or three-level grid, or a previous build of this cloud already knew) */
   int32_t dup_leaves;       /* last build: leaves of refined cells found to hold ONE position more than 32 times (quantised clouds): a search reads their
                              * 32 lowest indices only */
+  int32_t presort_refine;   /* last build: refinements of the cell size decided from the sample BEFORE the first sort (0 .. 3; first builds of clouds the
+                             * sample found non-uniform); negative: the sort's own count overruled them (a cloud stored in spatial order) and the grid was
+                             * laid out again */
+  int32_t n_sorts;          /* last build: full sorts of the cloud it ran (1; more when the cell size was refined after a count, a sampled box or a
+                             * pooled pass had to be redone) */
+  int32_t ordered_input;    /* last build: 1 = the sample found the cloud stored in spatial order (of 64 consecutive points most share a block): regions and
+                             * cell size are then not taken from a sample */
 } pt_stats_t;
 
 /* ---- context ------------------------------------------------------------------------ */
@@ -143,7 +150,8 @@ int  pt_set_stream(pt_ctx*, void* hip_stream);
  * their grid empty, default), "tile_contrast" (1: on clouds with strong density contrast the tile kernel runs first, k <= 24, and the
  * wave kernel takes what it leaves; 0, default: a wave per target -- measured faster), "local_ids" (1: the next slab build -- ascending
  * global indices, or a slab pt_build_synth generates -- keeps positions in its records and its own attribute records only; see
- * pt_set_attributes_local). */
+ * pt_set_attributes_local), "presort_refine" (1, default: the first build of a big cloud the sample finds non-uniform refines its cell size
+ * from the sample's bound on the points per occupied cell, before the first sort; 0: after it, from the sort's count -- round 3's behaviour). */
 int  pt_set_param(pt_ctx*, const char* name, double value);
 const char* pt_last_error(pt_ctx*);
 int  pt_stats(pt_ctx*, pt_stats_t* out);

@@ -762,6 +762,51 @@ def test_uniformity_sample_decides_the_first_build(pkg, oracle):
         _check_exact(got2, want, name + " after forget")
 
 
+def test_first_build_takes_its_cell_size_from_the_sample(pkg, oracle):
+    """Round 4: a detail-transfer run builds its index ONCE, so the first build is the one that counts.  The sample taken before a cloud's first
+    sort also estimates the points per occupied cell (distinct cells seen per block -> cells occupied), and a cloud it finds far from uniform --
+    a surface -- gets the finer cell size before that sort instead of after it: one sort, not two ("presort_refine" = 0: round 3's behaviour).
+    A cloud stored in SPATIAL order gives itself away in the same sample (consecutive points share a block): nothing is taken from the sample
+    then -- exact passes, the sort's own count -- where the pooled pass 1 used to overflow and be redone.  Same neighbours as the oracle."""
+    rng = np.random.default_rng(97)
+    n, m, k = 3_000_000, 3000, 8
+    v = rng.standard_normal((3, n)).astype(np.float32); v /= np.linalg.norm(v, axis=0, keepdims=True)
+    shell = (0.5 + 0.45 * v + 1e-4 * rng.standard_normal((3, n)).astype(np.float32)).astype(np.float32)
+    uni = rng.random((3, n), dtype=np.float32)
+    key = (uni[0] * 32).astype(np.int32) * 1024 + (uni[1] * 32).astype(np.int32) * 32 + (uni[2] * 32).astype(np.int32)
+    ordered = np.ascontiguousarray(uni[:, np.argsort(key, kind="stable")])
+    t_shell = (shell[:, :m] + np.float32(1e-3)).astype(np.float32)
+    t_uni = rng.random((3, m), dtype=np.float32)
+    seen = {}
+    for name, src, tgt in (("shell", shell, t_shell), ("ordered", ordered, t_uni), ("uniform", uni, t_uni)):
+        want = oracle.KdTree(src).query(tgt, k)
+        for pre in (1, 0):
+            with pkg.PointsTransfer(device=0, k_hint=k) as p:
+                p.set_param("pool_min_points", 1)
+                p.set_param("presort_refine", pre)
+                p.build(src)
+                st = p.stats()
+                seen[(name, pre)] = st
+                _check_exact(p.query(tgt, k), want, "%s presort=%d" % (name, pre))
+                p.rebuild()                                                     # the finished build left its cell size behind: one sort, nothing asked
+                st2 = p.stats()
+                assert st2["n_sorts"] == 1 and st2["presort_refine"] == 0 and st2["uniform_probe"] == 0, (name, pre, st2)
+                assert st2["grid_dim"][:] == st["grid_dim"][:], (name, st["grid_dim"][:], st2["grid_dim"][:])
+                p.set_param("forget", 1); p.rebuild()
+                st3 = p.stats()
+                assert (st3["n_sorts"], st3["presort_refine"], st3["ordered_input"]) == (st["n_sorts"], st["presort_refine"], st["ordered_input"]), (name, pre, st3)
+                _check_exact(p.query(tgt, k), want, "%s presort=%d after forget" % (name, pre))
+    a, b = seen[("shell", 1)], seen[("shell", 0)]
+    assert a["uniform_probe"] == -1 and a["presort_refine"] >= 1 and a["n_sorts"] == 1 and a["ordered_input"] == 0, a
+    assert b["presort_refine"] == 0 and b["n_sorts"] >= 2 and b["n_refine"] >= 1, b
+    assert a["rho_occupied"] <= 1.3 * b["rho_occupied"], (a["rho_occupied"], b["rho_occupied"])      # as fine a grid as the counted refinement reaches
+    for pre in (1, 0):
+        o = seen[("ordered", pre)]
+        assert o["ordered_input"] == 1 and o["n_sorts"] == 1 and o["pass1_pooled"] == 0 and o["pass2_pooled"] == 0 and o["presort_refine"] == 0, o
+        u = seen[("uniform", pre)]
+        assert u["ordered_input"] == 0 and u["uniform_probe"] == 1 and u["n_sorts"] == 1 and u["presort_refine"] == 0 and u["pass2_pooled"] == 1, u
+
+
 def test_wrong_sampled_box_and_pool_overflow_in_one_build(pkg, oracle):
     """Two guesses of one build fail together: the sampled bounding box misses an outlier AND the pooled pass 1's sampled bin regions
     overflow (every point outside the sampled runs sits in one clump).  rebuild() restarts itself once per failed guess; the result is
