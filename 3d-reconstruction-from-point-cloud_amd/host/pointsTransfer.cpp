@@ -208,7 +208,7 @@ int main(int argc, char** argv) {
       j << "{\"synthetic\": {\"n\": " << syn_n << ", \"m\": " << M << ", \"seed\": " << syn_seed << ", \"clustered\": " << (syn_dist == PT_DIST_CLUSTERED ? 1 : 0) << "}, \"k\": " << K
         << ", \"pt_stats\": {\"ms_build\": " << st.ms_build << ", \"ms_sort_targets\": " << st.ms_sort_targets << ", \"ms_query\": " << st.ms_query << ", \"grid_dim\": [" << st.grid_dim[0] << ", "
         << st.grid_dim[1] << ", " << st.grid_dim[2] << "], \"n_levels\": " << st.n_levels << ", \"pass1_pooled\": " << st.pass1_pooled << ", \"pass2_pooled\": " << st.pass2_pooled
-        << ", \"uniform_probe\": " << st.uniform_probe << ", \"n_leftover\": " << st.n_leftover << ", \"n_wave\": " << st.n_wave << ", \"device_bytes\": " << st.device_bytes
+        << ", \"uniform_probe\": " << st.uniform_probe << ", \"presort_refine\": " << st.presort_refine << ", \"n_sorts\": " << st.n_sorts << ", \"ordered_input\": " << st.ordered_input << ", \"n_leftover\": " << st.n_leftover << ", \"n_wave\": " << st.n_wave << ", \"device_bytes\": " << st.device_bytes
         << ", \"targets_per_second_device\": " << (st.ms_build + st.ms_sort_targets + st.ms_query > 0 ? (double)M / ((st.ms_build + st.ms_sort_targets + st.ms_query) * 1e-3) : 0.0) << "}}\n";
     }
     std::cout << "Output time: " << since(t_task) << " seconds" << std::endl;
