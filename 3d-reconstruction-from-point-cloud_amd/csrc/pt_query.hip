@@ -699,14 +699,17 @@ struct WaveScan {
   uint32_t nv = 0, nn = 0, nmerge = 0;     // instrumented build: steps of 64 records, nodes entered, sort-merges
 #endif
 
-  __device__ void reset() { ld = INFINITY; li = PT_NOIDX_U; lim_d = bnd_d; lim_i = PT_NOIDX_U; npend = 0; set_lim32(); }
-  __device__ void refresh() {
-    const double kd = readlane_f64(ld, k - 1);
-    const uint32_t ki = readlane_u32(li, k - 1);
-    if (key_lt_flat(kd, ki, bnd_d, PT_NOIDX_U)) { lim_d = kd; lim_i = ki; }
-    else { lim_d = bnd_d; lim_i = PT_NOIDX_U; }
-    set_lim32();
-  }
+  // THE LIST (round 4, second form).  Rounds 2 - 4 kept the k best SORTED across the lanes and paid a 27-stage bitonic sort-merge (361 VALU
+  // instructions) for every 16 - 48 candidates, 4.5 of them per sheet target of config 5 -- 46 % of a kernel that is bound by VALU issue (32
+  // more fp32 instructions per step of 64 records cost their full 3 cycles each: tools/ab_c5.sh, -DPT_WABLATE).  Nothing needs the order
+  // before the end: a scan needs the k-th smallest key, as its limit, and somewhere to keep the k best.  So the lanes hold an UNSORTED POOL
+  // (an empty lane: +inf, NOIDX), candidates collect in the wave's 64 LDS slots as before, and a flush
+  //   places them into free lanes (lane j, the r-th free one, reads slot r: one prefix count, two LDS reads),
+  //   selects the k-th smallest key of the pool by pivoting (a lane's key against all: one ballot and a count per probe, ~ 8 probes of ~ 6
+  //   VALU + scalar work on random data; every decision is scalar), makes it the limit and empties the lanes beyond it:
+  // ~ 70 VALU instructions instead of 361.  One 21-stage sort of the pool at the very end puts rank i into lane i for the output.
+  uint32_t npool;              // entries in the pool (wave-uniform)
+  __device__ void reset() { ld = INFINITY; li = PT_NOIDX_U; lim_d = bnd_d; lim_i = PT_NOIDX_U; npend = 0; npool = 0; set_lim32(); }
   // one step's 64 records: fp32 clouds look at the fp32 distance first
   __device__ __forceinline__ void step(const Rec& r, bool have) {
     if constexpr (PRE32) {
@@ -717,21 +720,6 @@ struct WaveScan {
     uint32_t id = PT_NOIDX_U;
     if (have) { d = dist2(q, r); id = r.id; }
     offer(d, id);
-  }
-  // (xd, xi) wave-uniform.  The entries that sort after it are a run of lanes [p, 63] (the list is sorted): they shift up one lane
-  // -- DPP moves executed by THOSE lanes only (lane p reads lane p - 1, which is switched off: bound_ctrl hands it a 0 that the
-  // next line overwrites) -- and lane p takes the new entry by v_writelane.  ~25 instructions; the compare-everything-and-select
-  // form of the same was ~58, and insertions are two thirds of this kernel's instructions on dense data.
-  // Returns the lane the entry went to (64: nowhere).
-  __device__ int insert(double xd, uint32_t xi) {
-    const bool gt = key_lt_flat(xd, xi, ld, li);
-    const unsigned long long after = __ballot(gt);
-    if (!after) return 64;                                   // wave-uniform
-    const int p = __ffsll((long long)after) - 1;
-    if (gt) { ld = dpp_f64<DPP_WAVE_SHR1>(ld); li = dpp_u32<DPP_WAVE_SHR1>(li); }
-    ld = __hiloint2double((int)writelane_u32((uint32_t)__double2hiint(ld), (uint32_t)__double2hiint(xd), p), (int)writelane_u32((uint32_t)__double2loint(ld), (uint32_t)__double2loint(xd), p));
-    li = writelane_u32(li, xi, p);
-    return p;
   }
   // Many candidates at once (the first steps of a target: with fewer than k points seen every record is one): sort the 64 candidate
   // slots across the lanes (bitonic, 21 exchange stages), take the 64 smallest of list and candidates (list[i] against candidate
@@ -768,70 +756,69 @@ struct WaveScan {
     if (k2 > 2) exchange<2>(xd, xi, ((l & 2) == 0) == up);
     exchange<1>(xd, xi, ((l & 1) == 0) == up);
   }
-  // The merge itself is ONE function in the code object, called (values in, values out: nothing of the scan's state goes through
-  // memory) from wherever a scan offers candidates: inlined at every such place, its 27 stages pushed the kernel out of the
-  // instruction cache and the registers -- 480 ms at C5's shape against 325 ms called, 365 ms with the rolled ds_bpermute form.
-  struct KeyDI { double d; uint32_t i; };
-  __device__ __attribute__((noinline)) static KeyDI merge_core(double ld_, uint32_t li_, double cd, uint32_t ci) {
-    WaveScan t;
-    t.lane = (int)__lane_id();
-#pragma unroll
-    for (int k2 = 2; k2 <= 64; k2 <<= 1) t.stages(cd, ci, k2, t.lane);      // candidates sorted across the lanes
-    const double rd = __shfl(cd, 63 - t.lane);
-    const uint32_t ri = (uint32_t)__shfl((int)ci, 63 - t.lane);
-    if (key_lt_flat(rd, ri, ld_, li_)) { ld_ = rd; li_ = ri; }              // the 64 smallest of list and candidates: a bitonic sequence
-    t.stages(ld_, li_, 64, t.lane);
-    return KeyDI{ld_, li_};
+#ifndef PT_PEND_FLUSH
+#define PT_PEND_FLUSH 40
+#endif
+  static constexpr int PEND_FLUSH = PT_PEND_FLUSH;
+  // pool entries in [first, first + take) of the slots -> the first `take` free lanes (take <= 64 - npool)
+  __device__ __forceinline__ void place(uint32_t first, uint32_t take) {
+    const bool fre = li == PT_NOIDX_U && ld == INFINITY;
+    const unsigned long long F = __ballot(fre);
+    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(F >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)F, 0u));
+    if (fre && r < take) { ld = pend_d[first + r]; li = pend_i[first + r]; }
+    npool += take;
   }
-  __device__ __forceinline__ void merge64(double cd, uint32_t ci) {
+  // npool >= k: the k-th smallest key of the pool becomes the limit, the lanes beyond it are emptied.  Keys are distinct (indices).
+  // ONE function in the code object, values in and values out (as the sort-merge was: nothing of the scan's state goes through memory).
+  struct Sel { double ld; uint32_t li; double td; uint32_t ti; };
+  __device__ __attribute__((noinline)) static Sel select_core(double ld_, uint32_t li_, uint32_t k_) {
+    unsigned long long A = __ballot(!(li_ == PT_NOIDX_U && ld_ == INFINITY));     // the lanes still in question
+    uint32_t need = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_);            // rank sought among them (an argument arrives in a VGPR: said to be uniform, or the whole loop is compiled for divergent lanes)
+    double td = INFINITY;
+    uint32_t ti = PT_NOIDX_U;
+    bool found = false;
+    int flip = 0;
+    while (!found) {                                        // wave-uniform: A and need are scalars; A shrinks with every probe
+      // pivot: the lowest / the highest lane in question by turns (records arrive in memory order, not by distance; a pool that happens
+      // to be sorted one way round still halves every other probe)
+      const int p = flip ? 63 - __builtin_clzll(A) : __ffsll((long long)A) - 1;
+      flip ^= 1;
+      const double pd = readlane_f64(ld_, p);
+      const uint32_t pi = readlane_u32(li_, p);
+      const unsigned long long L = __ballot(key_lt_flat(ld_, li_, pd, pi)) & A;
+      const uint32_t cl = (uint32_t)__popcll(L);
+      if (need <= cl) A = L;
+      else if (need == cl + 1u) { td = pd; ti = pi; found = true; }
+      else { need -= cl + 1u; A &= ~L; A &= ~(1ull << p); }
+    }
+    if (key_lt_flat(td, ti, ld_, li_)) { ld_ = INFINITY; li_ = PT_NOIDX_U; }       // beyond the k-th: out
+    return Sel{ld_, li_, td, ti};
+  }
+  __device__ __forceinline__ void select_prune() {
 #ifdef PT_VISITS
     ++nmerge;
 #endif
-    const KeyDI r = merge_core(ld, li, cd, ci);
-    ld = r.d; li = r.i;
-  }
-#ifndef PT_MERGE_MIN
-#define PT_MERGE_MIN 16
-#endif
-#ifndef PT_PEND_FLUSH
-#define PT_PEND_FLUSH 48
-#endif
-#ifndef PT_PEND_MIN_K
-#define PT_PEND_MIN_K 12
-#endif
-  static constexpr int MERGE_MIN = PT_MERGE_MIN;
-  // Steps with few candidates -- the long tail of a dense cell: k ln(n / k) of them, one or two per step -- do not insert them one by
-  // one (~35 instructions each, most of this kernel's instructions at k = 32): the candidates are set aside in LDS (a ballot, a
-  // prefix count, one exec-masked write) and the list takes PEND_FLUSH of them in ONE sort-merge.  The limit stays where the last
-  // merge left it meanwhile -- an upper bound of the final k-th distance like any other, so nothing is lost; ~35 % more records
-  // pass it, and the whole costs ~40 % fewer instructions at k = 32, a third fewer at k = 20, none at k = 8 (simulated on random
-  // orders; hence PEND_MIN_K).  Whoever DECIDES by the limit (which cells to read next, whether the ring was the last) calls
-  // flush() first.
-  static constexpr int PEND_FLUSH = PT_PEND_FLUSH, PEND_MIN_K = PT_PEND_MIN_K;
-  static_assert(PEND_FLUSH + MERGE_MIN - 2 < 64, "the slots of one wave");
-  __device__ __forceinline__ void insert_each(double d, uint32_t id, unsigned long long mask) {
-    while (mask) {                                          // wave-uniform
-      const int j = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      const double xd = readlane_f64(d, j);
-      const uint32_t xi = readlane_u32(id, j);
-      // (no second look at the limit: a candidate that no longer beats it lands beyond rank k - 1, where it is harmless)
-      if (insert(xd, xi) < k) refresh();
-    }
+    const Sel r = select_core(ld, li, (uint32_t)k);
+    ld = r.ld; li = r.li;
+    npool = (uint32_t)k;
+    lim_d = r.td; lim_i = r.ti;                             // (<= bnd_d: nothing beyond the caller's bound was ever offered)
+    set_lim32();
   }
   __device__ __forceinline__ void flush() {
     if (!npend) return;                                     // wave-uniform
-    const uint32_t n = npend;                               // < 64: PEND_FLUSH - 1 + MERGE_MIN - 1 at most
+    const uint32_t n = npend;                               // <= 64
     npend = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the slots were written by this wave's own lanes: LDS keeps a wave's order
     __builtin_amdgcn_wave_barrier();
-    double d = INFINITY;
-    uint32_t id = PT_NOIDX_U;
-    if ((uint32_t)lane < n) { d = pend_d[lane]; id = pend_i[lane]; }
+    uint32_t done = 0;
+    while (done < n) {                                      // wave-uniform; one trip unless more arrived than there are free lanes
+      const uint32_t take = min(n - done, 64u - npool);
+      place(done, take);
+      done += take;
+      if (npool >= (uint32_t)k) select_prune();
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // ... and the next round's writes stay behind these reads
     __builtin_amdgcn_wave_barrier();
-    if (n >= (uint32_t)MERGE_MIN) { merge64(d, id); refresh(); }
-    else insert_each(d, id, (1ull << n) - 1ull);
   }
   // one candidate per lane (d = +inf for lanes without one)
   __device__ __forceinline__ void offer(double d, uint32_t id) {
@@ -839,16 +826,17 @@ struct WaveScan {
     const unsigned long long mask = __ballot(pass);
     if (!mask) return;                                      // wave-uniform (as every branch below)
     const uint32_t c = (uint32_t)__popcll(mask);
-    if (c >= (uint32_t)MERGE_MIN) {
-      merge64(pass ? d : INFINITY, pass ? id : PT_NOIDX_U);
-      refresh();
-      return;
-    }
-    if (k < PEND_MIN_K) { insert_each(d, id, mask); return; }
+    if (npend + c > 64u) flush();                           // (no room in the slots: the pool takes what is there first)
     const uint32_t slot = npend + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     if (pass) { pend_d[slot] = d; pend_i[slot] = id; }
     npend += c;
     if (npend >= (uint32_t)PEND_FLUSH) flush();
+  }
+  // the end of a search: rank i into lane i (the empty lanes sort last)
+  __device__ void finish() {
+    flush();
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) stages(ld, li, k2, lane);
   }
   // WPF steps of loads are in flight while a step is ranked: with one, every step of 64 records cost a full memory latency (60 us
   // per target at 25 - 35 steps, measured: the steps' arithmetic is ~0.15 us)
@@ -1159,7 +1147,7 @@ __global__ __launch_bounds__(WG, HIER ? PT_WV_MINW_H : PT_WV_MINW) void knn_wave
     st = 0;
     { const int side = 2 * rr + 1; nst = (side * side * side - (side - 2) * (side - 2) * (side - 2) + 63) / 64; }
   }
-  W.flush();                                                // (the block sweep ends with candidates set aside)
+  W.finish();                                               // (the block sweep ends with candidates set aside; the pool is sorted for the output)
 #ifdef PT_VISITS
   asm volatile("" ::"v"(W.ld)); pt_ph[3] = wall_clock64();
 #endif
