@@ -29,6 +29,7 @@
 // Control flow is uniform inside a group (all lanes of a group / quad take every branch together), so cross-lane
 // operations never see an inactive partner; different groups of a wave diverge freely.
 #include "pt_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -671,6 +672,10 @@ __device__ inline float dist2_f32(float qx, float qy, float qz, const RecF& r) {
 template <class Rec> struct IsRecF { static constexpr bool value = false; };
 template <> struct IsRecF<RecF> { static constexpr bool value = true; };
 
+// __ballot(bool) goes through an integer compare: the compiler materialises the predicate (v_cndmask 0 / 1) and compares it with zero
+// again -- two VALU instructions per ballot in a kernel bound by VALU issue.  The builtin takes the condition's mask as it is.
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 template <class Rec>
 struct WaveScan {
   const Rec* __restrict__ src;
@@ -692,8 +697,7 @@ struct WaveScan {
   __device__ __forceinline__ void set_lim32() { lim32 = (float)(lim_d * 1.00000095367431640625) + 1e-30f; }
   int k, lane;
   // candidates set aside (k >= PEND_MIN_K): this wave's 64 slots in LDS and how many are taken (wave-uniform); see offer()
-  double* pend_d;
-  uint32_t* pend_i;
+  uint4* pend;                 // slot: (d2 low word, d2 high word, index, -)
   uint32_t npend;
 #ifdef PT_VISITS
   uint32_t nv = 0, nn = 0, nmerge = 0;     // instrumented build: steps of 64 records, nodes entered, sort-merges
@@ -713,13 +717,10 @@ struct WaveScan {
   // one step's 64 records: fp32 clouds look at the fp32 distance first
   __device__ __forceinline__ void step(const Rec& r, bool have) {
     if constexpr (PRE32) {
-      const bool near32 = have && dist2_f32(qf[0], qf[1], qf[2], r) <= lim32;
-      if (!__ballot(near32)) return;                        // wave-uniform
+      const bool near32 = have & (dist2_f32(qf[0], qf[1], qf[2], r) <= lim32);      // (no short circuit: a branch around six instructions costs more than they do)
+      if (!ballot64(near32)) return;                        // wave-uniform
     }
-    double d = INFINITY;
-    uint32_t id = PT_NOIDX_U;
-    if (have) { d = dist2(q, r); id = r.id; }
-    offer(d, id);
+    offer(dist2(q, r), r.id, have);                         // (lanes without a record computed on whatever record their registers held: `have` keeps them out)
   }
   // Many candidates at once (the first steps of a target: with fewer than k points seen every record is one): sort the 64 candidate
   // slots across the lanes (bitonic, 21 exchange stages), take the 64 smallest of list and candidates (list[i] against candidate
@@ -757,22 +758,22 @@ struct WaveScan {
     exchange<1>(xd, xi, ((l & 1) == 0) == up);
   }
 #ifndef PT_PEND_FLUSH
-#define PT_PEND_FLUSH 40
+#define PT_PEND_FLUSH 24
 #endif
   static constexpr int PEND_FLUSH = PT_PEND_FLUSH;
   // pool entries in [first, first + take) of the slots -> the first `take` free lanes (take <= 64 - npool)
   __device__ __forceinline__ void place(uint32_t first, uint32_t take) {
     const bool fre = li == PT_NOIDX_U && ld == INFINITY;
-    const unsigned long long F = __ballot(fre);
+    const unsigned long long F = ballot64(fre);
     const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(F >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)F, 0u));
-    if (fre && r < take) { ld = pend_d[first + r]; li = pend_i[first + r]; }
+    if (fre && r < take) { const uint4 v = pend[first + r]; ld = __hiloint2double((int)v.y, (int)v.x); li = v.z; }
     npool += take;
   }
   // npool >= k: the k-th smallest key of the pool becomes the limit, the lanes beyond it are emptied.  Keys are distinct (indices).
   // ONE function in the code object, values in and values out (as the sort-merge was: nothing of the scan's state goes through memory).
   struct Sel { double ld; uint32_t li; double td; uint32_t ti; };
   __device__ __attribute__((noinline)) static Sel select_core(double ld_, uint32_t li_, uint32_t k_) {
-    unsigned long long A = __ballot(!(li_ == PT_NOIDX_U && ld_ == INFINITY));     // the lanes still in question
+    unsigned long long A = ballot64(!(li_ == PT_NOIDX_U && ld_ == INFINITY));     // the lanes still in question
     uint32_t need = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_);            // rank sought among them (an argument arrives in a VGPR: said to be uniform, or the whole loop is compiled for divergent lanes)
     double td = INFINITY;
     uint32_t ti = PT_NOIDX_U;
@@ -785,7 +786,7 @@ struct WaveScan {
       flip ^= 1;
       const double pd = readlane_f64(ld_, p);
       const uint32_t pi = readlane_u32(li_, p);
-      const unsigned long long L = __ballot(key_lt_flat(ld_, li_, pd, pi)) & A;
+      const unsigned long long L = ballot64(key_lt_flat(ld_, li_, pd, pi)) & A;
       const uint32_t cl = (uint32_t)__popcll(L);
       if (need <= cl) A = L;
       else if (need == cl + 1u) { td = pd; ti = pi; found = true; }
@@ -821,14 +822,14 @@ struct WaveScan {
     __builtin_amdgcn_wave_barrier();
   }
   // one candidate per lane (d = +inf for lanes without one)
-  __device__ __forceinline__ void offer(double d, uint32_t id) {
-    const bool pass = key_lt_flat(d, id, lim_d, lim_i) && !(d > bnd_d);
-    const unsigned long long mask = __ballot(pass);
+  __device__ __forceinline__ void offer(double d, uint32_t id, bool have) {
+    const bool pass = have & key_lt_flat(d, id, lim_d, lim_i) & !(d > bnd_d);
+    const unsigned long long mask = ballot64(pass);
     if (!mask) return;                                      // wave-uniform (as every branch below)
     const uint32_t c = (uint32_t)__popcll(mask);
     if (npend + c > 64u) flush();                           // (no room in the slots: the pool takes what is there first)
     const uint32_t slot = npend + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    if (pass) { pend_d[slot] = d; pend_i[slot] = id; }
+    if (pass) pend[slot] = make_uint4((uint32_t)__double2loint(d), (uint32_t)__double2hiint(d), id, 0u);      // one 16-byte LDS write
     npend += c;
     if (npend >= (uint32_t)PEND_FLUSH) flush();
   }
@@ -844,23 +845,38 @@ struct WaveScan {
 #define PT_WPF 1
 #endif
   static constexpr int WPF = PT_WPF;
+  // Two register sets take turns (a is ranked while b's load is in flight and the other way round): with one set and a copy per step the
+  // compiler waits for a load right after issuing it, to move its words into the set the ranking reads.  For the same reason a 16-byte record
+  // travels as ONE four-word value (four consecutive registers, the load's own destination) until the step takes it apart: as a struct of four
+  // scalars its index word was given a register elsewhere, and the move into it waited for the load.
+  using Vec = typename std::conditional<IsRecF<Rec>::value, float4, Rec>::type;
+  __device__ __forceinline__ static Vec loadv(const Rec* p) {
+    if constexpr (IsRecF<Rec>::value) return *reinterpret_cast<const float4*>(p); else return *p;
+  }
+  __device__ __forceinline__ void stepv(const Vec& v, bool have) {
+    if constexpr (IsRecF<Rec>::value) { RecF r; r.x = v.x; r.y = v.y; r.z = v.z; r.id = __float_as_uint(v.w); step(r, have); }
+    else step(v, have);
+  }
   __device__ void range(uint32_t s, uint32_t e) {
-    Rec pq[WPF];
-#pragma unroll
-    for (int j = 0; j < WPF; ++j) {
-      const uint32_t p = s + (uint32_t)(j * 64 + lane);
-      if (p < e) pq[j] = src[p];
-    }
-    for (uint32_t base = s; base < e; base += 64u) {
+    // (every load is UNCONDITIONAL, its index clamped to the last record: a load under `if (p < e)` merges with the old value behind it, and the
+    //  copy that merge needs waits for the load on the spot -- the prefetch gone; lanes beyond the end rank a record twice and `have` discards it)
+    if (s >= e) return;                                     // wave-uniform
+    const uint32_t last = e - 1u;
+    Vec a = loadv(src + min(s + (uint32_t)lane, last)), b;
+    for (uint32_t base = s; base < e; base += 128u) {       // wave-uniform trip count, no early exit
       const uint32_t p = base + (uint32_t)lane;
-      const Rec r = pq[0];
-#pragma unroll
-      for (int j = 0; j + 1 < WPF; ++j) pq[j] = pq[j + 1];
-      if (p + (uint32_t)(WPF * 64) < e) pq[WPF - 1] = src[p + (uint32_t)(WPF * 64)];
+      b = loadv(src + min(p + 64u, last));
 #ifdef PT_VISITS
       ++nv;
 #endif
-      step(r, p < e);
+      stepv(a, p < e);
+      if (base + 64u < e) {                                 // wave-uniform
+        a = loadv(src + min(p + 128u, last));
+#ifdef PT_VISITS
+        ++nv;
+#endif
+        stepv(b, p + 64u < e);
+      }
     }
   }
   // Up to 64 runs of records as ONE stream: lane j brings its run's first record S and length C (0: none); virtual record v of the
@@ -878,7 +894,7 @@ struct WaveScan {
     uint32_t c_lo = 0, c_hi = 0, c_S = 0;
     auto locate = [&](uint32_t v) -> uint32_t {             // address of virtual record v (any value for v >= T)
       const bool out = v < T && v >= c_hi;
-      if (__ballot(out) != 0ull) {                          // wave-uniform
+      if (ballot64(out) != 0ull) {                          // wave-uniform
         int sg = 0;                                         // number of runs that end at or before v
 #pragma unroll
         for (int step = 32; step >= 1; step >>= 1) {
@@ -891,24 +907,22 @@ struct WaveScan {
       }
       return c_S + (v - c_lo);
     };
-    Rec pq[WPF];
-#pragma unroll
-    for (int j = 0; j < WPF; ++j) {
-      const uint32_t v = (uint32_t)(j * 64 + lane);
-      const uint32_t a = locate(v);
-      if (v < T) pq[j] = src[a];
-    }
-    for (uint32_t base = 0; base < T; base += 64u) {
+    const uint32_t last = T - 1u;                           // two register sets taking turns and unconditional loads, as in range()
+    Vec a = loadv(src + locate(min((uint32_t)lane, last))), b;
+    for (uint32_t base = 0; base < T; base += 128u) {       // wave-uniform trip count, no early exit
       const uint32_t v = base + (uint32_t)lane;
-      const Rec r = pq[0];
-#pragma unroll
-      for (int j = 0; j + 1 < WPF; ++j) pq[j] = pq[j + 1];
-      const uint32_t a = locate(v + (uint32_t)(WPF * 64));
-      if (v + (uint32_t)(WPF * 64) < T) pq[WPF - 1] = src[a];
+      b = loadv(src + locate(min(v + 64u, last)));
 #ifdef PT_VISITS
       ++nv;
 #endif
-      step(r, v < T);
+      stepv(a, v < T);
+      if (base + 64u < T) {                                 // wave-uniform
+        a = loadv(src + locate(min(v + 128u, last)));
+#ifdef PT_VISITS
+        ++nv;
+#endif
+        stepv(b, v + 64u < T);
+      }
     }
   }
   __device__ double gap2(int a, double lo, double hi) const {
@@ -934,7 +948,7 @@ struct WaveScan {
       if (rx >= 0.0 && rx < 8.0 && ry >= 0.0 && ry < 8.0 && rz >= 0.0 && rz < 8.0) own = (uint32_t)(((int)rz << 6) | ((int)ry << 3) | (int)rx);
       const double fy = (double)(lane & 7), fz = (double)(lane >> 3);          // my row (sy, sz) = (lane & 7, lane >> 3)
       const double s2 = gap2(1, oy + fy * w, oy + (fy + 1.0) * w) + gap2(2, oz + fz * w, oz + (fz + 1.0) * w);
-      live = __ballot(!(s2 * h2 > lim_d)) & ((unsigned long long)N[PT_NODE_ROWMASK] | ((unsigned long long)N[PT_NODE_ROWMASK + 1] << 32));
+      live = ballot64(!(s2 * h2 > lim_d)) & ((unsigned long long)N[PT_NODE_ROWMASK] | ((unsigned long long)N[PT_NODE_ROWMASK + 1] << 32));
     }
     bool first = own != 0xFFFFFFFFu;
     while (first || live) {                                 // wave-uniform
@@ -1015,11 +1029,10 @@ __global__ __launch_bounds__(WG, HIER ? PT_WV_MINW_H : PT_WV_MINW) void knn_wave
   const unsigned long long pt_t0 = wall_clock64();
   unsigned long long pt_ph[4] = {pt_t0, pt_t0, pt_t0, pt_t0};      // cells known / own cell done / ring-1 stream done / search done
 #endif
-  __shared__ double pend_d[WG / 64][64];
-  __shared__ uint32_t pend_i[WG / 64][64];
+  __shared__ uint4 pend[WG / 64][64];
   WaveScan<Rec> W;
   W.src = src; W.nodes = ha.nodes; W.k = k; W.lane = lane;
-  W.pend_d = pend_d[threadIdx.x >> 6]; W.pend_i = pend_i[threadIdx.x >> 6];
+  W.pend = pend[threadIdx.x >> 6];
   W.q[0] = (double)tr.x; W.q[1] = (double)tr.y; W.q[2] = (double)tr.z;
   W.qf[0] = (float)tr.x; W.qf[1] = (float)tr.y; W.qf[2] = (float)tr.z;      // (used by fp32 clouds only, whose targets are fp32 too)
   W.h2 = gp.h * gp.h;
@@ -1099,7 +1112,7 @@ __global__ __launch_bounds__(WG, HIER ? PT_WV_MINW_H : PT_WV_MINW) void knn_wave
     if (st < 0) { asm volatile("" ::"v"(W.ld)); pt_ph[2] = wall_clock64(); }
 #endif
     if constexpr (HIER) {
-      unsigned long long want = __ballot(on && nid);
+      unsigned long long want = ballot64(on && nid);
       while (want) {                                        // wave-uniform
         const int i = __ffsll((long long)want) - 1;
         want &= want - 1;
