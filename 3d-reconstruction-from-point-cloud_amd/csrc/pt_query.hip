@@ -761,63 +761,74 @@ struct WaveScan {
 #define PT_PEND_FLUSH 24
 #endif
   static constexpr int PEND_FLUSH = PT_PEND_FLUSH;
-  // pool entries in [first, first + take) of the slots -> the first `take` free lanes (take <= 64 - npool)
-  __device__ __forceinline__ void place(uint32_t first, uint32_t take) {
-    const bool fre = li == PT_NOIDX_U && ld == INFINITY;
-    const unsigned long long F = ballot64(fre);
-    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(F >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)F, 0u));
-    if (fre && r < take) { const uint4 v = pend[first + r]; ld = __hiloint2double((int)v.y, (int)v.x); li = v.z; }
-    npool += take;
-  }
-  // npool >= k: the k-th smallest key of the pool becomes the limit, the lanes beyond it are emptied.  Keys are distinct (indices).
-  // ONE function in the code object, values in and values out (as the sort-merge was: nothing of the scan's state goes through memory).
-  struct Sel { double ld; uint32_t li; double td; uint32_t ti; };
-  __device__ __attribute__((noinline)) static Sel select_core(double ld_, uint32_t li_, uint32_t k_) {
-    unsigned long long A = ballot64(!(li_ == PT_NOIDX_U && ld_ == INFINITY));     // the lanes still in question
-    uint32_t need = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_);            // rank sought among them (an argument arrives in a VGPR: said to be uniform, or the whole loop is compiled for divergent lanes)
-    double td = INFINITY;
-    uint32_t ti = PT_NOIDX_U;
-    bool found = false;
-    int flip = 0;
-    while (!found) {                                        // wave-uniform: A and need are scalars; A shrinks with every probe
-      // pivot: the lowest / the highest lane in question by turns (records arrive in memory order, not by distance; a pool that happens
-      // to be sorted one way round still halves every other probe)
-      const int p = flip ? 63 - __builtin_clzll(A) : __ffsll((long long)A) - 1;
-      flip ^= 1;
-      const double pd = readlane_f64(ld_, p);
-      const uint32_t pi = readlane_u32(li_, p);
-      const unsigned long long L = ballot64(key_lt_flat(ld_, li_, pd, pi)) & A;
-      const uint32_t cl = (uint32_t)__popcll(L);
-      if (need <= cl) A = L;
-      else if (need == cl + 1u) { td = pd; ti = pi; found = true; }
-      else { need -= cl + 1u; A &= ~L; A &= ~(1ull << p); }
-    }
-    if (key_lt_flat(td, ti, ld_, li_)) { ld_ = INFINITY; li_ = PT_NOIDX_U; }       // beyond the k-th: out
-    return Sel{ld_, li_, td, ti};
-  }
-  __device__ __forceinline__ void select_prune() {
-#ifdef PT_VISITS
-    ++nmerge;
-#endif
-    const Sel r = select_core(ld, li, (uint32_t)k);
-    ld = r.ld; li = r.li;
-    npool = (uint32_t)k;
-    lim_d = r.td; lim_i = r.ti;                             // (<= bnd_d: nothing beyond the caller's bound was ever offered)
-    set_lim32();
-  }
-  __device__ __forceinline__ void flush() {
-    if (!npend) return;                                     // wave-uniform
-    const uint32_t n = npend;                               // <= 64
-    npend = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the slots were written by this wave's own lanes: LDS keeps a wave's order
-    __builtin_amdgcn_wave_barrier();
+  // The flush is ONE function in the code object (as the sort-merge was), values in and values out -- nothing of the scan's state goes through
+  // memory: inlined at every place a scan may flush (65 of them in the descending variant) it pushed other members out of line, and a member
+  // called as a function takes `this`, i.e. the whole scan state moves to scratch memory (26 -> 84 ms for that launch at config 5's shape).
+  //   place:  slots [done, done + take) -> the first `take` free lanes (lane j, the r-th free one, reads slot r)
+  //   select: the k-th smallest key of the pool by pivoting -- the lowest / the highest lane in question by turns (records arrive in memory
+  //           order, not by distance; a pool that happens to be sorted one way round still halves every other probe); every decision is
+  //           scalar, the set in question shrinks with every probe; the key found is the limit, the lanes beyond it are emptied.
+  // Arguments arrive in VGPRs: the wave-uniform ones are said to be uniform, or the loops are compiled for divergent lanes.
+  struct Pool { double ld; uint32_t li; uint32_t npool; double lim_d; uint32_t lim_i; uint32_t nsel; };
+  __device__ __attribute__((noinline)) static Pool flush_core(double ld_, uint32_t li_, uint32_t npool_, uint32_t n_, uint32_t k_, double lim_d_, uint32_t lim_i_,
+                                                              const uint4* pend_) {
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_), k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_);
+    uint32_t npool = (uint32_t)__builtin_amdgcn_readfirstlane((int)npool_), nsel = 0;
+    double lim_d = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(lim_d_)), __builtin_amdgcn_readfirstlane(__double2loint(lim_d_)));
+    uint32_t lim_i = (uint32_t)__builtin_amdgcn_readfirstlane((int)lim_i_);
+    const uint4* pend = reinterpret_cast<const uint4*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)pend_ >> 32)) << 32) |
+                                                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)pend_));
     uint32_t done = 0;
     while (done < n) {                                      // wave-uniform; one trip unless more arrived than there are free lanes
       const uint32_t take = min(n - done, 64u - npool);
-      place(done, take);
+      {
+        const bool fre = li_ == PT_NOIDX_U && ld_ == INFINITY;
+        const unsigned long long F = ballot64(fre);
+        const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(F >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)F, 0u));
+        if (fre && r < take) { const uint4 v = pend[done + r]; ld_ = __hiloint2double((int)v.y, (int)v.x); li_ = v.z; }
+        npool += take;
+      }
       done += take;
-      if (npool >= (uint32_t)k) select_prune();
+      if (npool >= k) {
+        ++nsel;
+        unsigned long long A = ballot64(!(li_ == PT_NOIDX_U && ld_ == INFINITY));      // the lanes still in question
+        uint32_t need = k;                                                             // rank sought among them
+        double td = INFINITY;
+        uint32_t ti = PT_NOIDX_U;
+        bool found = false;
+        int flip = 0;
+        while (!found) {                                    // wave-uniform: A and need are scalars; A shrinks with every probe
+          const int p = flip ? 63 - __builtin_clzll(A) : __ffsll((long long)A) - 1;
+          flip ^= 1;
+          const double pd = readlane_f64(ld_, p);
+          const uint32_t pi = readlane_u32(li_, p);
+          const unsigned long long L = ballot64(key_lt_flat(ld_, li_, pd, pi)) & A;
+          const uint32_t cl = (uint32_t)__popcll(L);
+          if (need <= cl) A = L;
+          else if (need == cl + 1u) { td = pd; ti = pi; found = true; }
+          else { need -= cl + 1u; A &= ~L; A &= ~(1ull << p); }
+        }
+        if (key_lt_flat(td, ti, ld_, li_)) { ld_ = INFINITY; li_ = PT_NOIDX_U; }       // beyond the k-th: out
+        npool = k;
+        lim_d = td; lim_i = ti;                             // (<= the caller's bound: nothing beyond it was ever offered)
+      }
     }
+    return Pool{ld_, li_, npool, lim_d, lim_i, nsel};
+  }
+  __device__ __forceinline__ void flush() {
+    if (!npend) return;                                     // wave-uniform
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the slots were written by this wave's own lanes: LDS keeps a wave's order
+    __builtin_amdgcn_wave_barrier();
+    const Pool r = flush_core(ld, li, npool, npend, (uint32_t)k, lim_d, lim_i, pend);
+    npend = 0;
+    ld = r.ld; li = r.li;
+    npool = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.npool);
+    lim_d = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(r.lim_d)), __builtin_amdgcn_readfirstlane(__double2loint(r.lim_d)));
+    lim_i = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.lim_i);
+    set_lim32();
+#ifdef PT_VISITS
+    nmerge += (uint32_t)__builtin_amdgcn_readfirstlane((int)r.nsel);
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // ... and the next round's writes stay behind these reads
     __builtin_amdgcn_wave_barrier();
   }
@@ -834,10 +845,24 @@ struct WaveScan {
     if (npend >= (uint32_t)PEND_FLUSH) flush();
   }
   // the end of a search: rank i into lane i (the empty lanes sort last)
-  __device__ void finish() {
+  // (the pool's <= k entries are gathered in the low lanes first -- through the slots, free by now -- so that the sort spans 8, 16 or 32 lanes:
+  //  6, 10 or 15 exchange stages instead of the 21 that 64 lanes take)
+  __device__ __forceinline__ void finish() {                // (forced: called as a function it takes `this`, and the whole scan state moves to scratch memory)
     flush();
-#pragma unroll
-    for (int k2 = 2; k2 <= 64; k2 <<= 1) stages(ld, li, k2, lane);
+    const bool has = !(li == PT_NOIDX_U && ld == INFINITY);
+    const unsigned long long M = ballot64(has);
+    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+    if (has) pend[r] = make_uint4((uint32_t)__double2loint(ld), (uint32_t)__double2hiint(ld), li, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    ld = INFINITY; li = PT_NOIDX_U;
+    if ((uint32_t)lane < (uint32_t)__popcll(M)) { const uint4 v = pend[lane]; ld = __hiloint2double((int)v.y, (int)v.x); li = v.z; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    stages(ld, li, 2, lane); stages(ld, li, 4, lane); stages(ld, li, 8, lane);
+    if (k > 8) stages(ld, li, 16, lane);                    // wave-uniform
+    if (k > 16) stages(ld, li, 32, lane);
+    if (k > 32) stages(ld, li, 64, lane);
   }
   // WPF steps of loads are in flight while a step is ranked: with one, every step of 64 records cost a full memory latency (60 us
   // per target at 25 - 35 steps, measured: the steps' arithmetic is ~0.15 us)
@@ -857,7 +882,7 @@ struct WaveScan {
     if constexpr (IsRecF<Rec>::value) { RecF r; r.x = v.x; r.y = v.y; r.z = v.z; r.id = __float_as_uint(v.w); step(r, have); }
     else step(v, have);
   }
-  __device__ void range(uint32_t s, uint32_t e) {
+  __device__ __forceinline__ void range(uint32_t s, uint32_t e) {
     // (every load is UNCONDITIONAL, its index clamped to the last record: a load under `if (p < e)` merges with the old value behind it, and the
     //  copy that merge needs waits for the load on the spot -- the prefetch gone; lanes beyond the end rank a record twice and `have` discards it)
     if (s >= e) return;                                     // wave-uniform
@@ -883,7 +908,7 @@ struct WaveScan {
   // stream is record v - P[j] of the run j whose prefix interval holds v.  64 records per step whatever the runs' lengths, and the
   // next step's loads are in flight while this one is ranked -- a run costs no memory latency of its own (cell by cell, the 27
   // cells of ring 1 cost 27: 40 us per target, measured).  No pruning inside the stream: the caller decides the runs beforehand.
-  __device__ void stream(uint32_t S, uint32_t C) {
+  __device__ __forceinline__ void stream(uint32_t S, uint32_t C) {
     const uint32_t pin = wave_incl_scan(C), pex = pin - C;
     const uint32_t T = readlane_u32(pin, 63);
     if (!T) return;                                         // wave-uniform
