@@ -1555,6 +1555,44 @@ def test_generated_slabs_in_index_order_carry_their_own_attributes(pkg, oracle, 
         p.close()
 
 
+def test_generated_slab_at_c4_scale_local_ids_equal_global_ids(pkg, oracle):
+    """What one rank of `bench.py --gpus 8` builds at BASELINE config 4: its eighth of the 1e9-point cloud, GENERATED in index order with
+    positions in its records and its own 125 M attribute records (3.9 M workgroup counts through the scan).  The same slab generated the
+    round-3 way (global indices in the records, the whole 16-GB table) must give the same lists bit for bit and the same fused blend; the
+    indices are global ones of slab points at the distances reported (regenerated through the oracle)."""
+    import torch
+    n_total, m, k, seed = 1_000_000_000, 200_000, 8, 0xC4
+    lo, hi = 0.375, 0.5
+    with pkg.PointsTransfer(device=0, k_hint=k) as p:                            # the slab's targets once (a generated slab's ORDER is whatever the atomics made it)
+        p.targets_synth(m * 8, seed, slab_axis=0, slab_lo=lo, slab_hi=hi)
+        mm = p.num_targets
+        tx = torch.empty((3, mm), dtype=torch.float32, device="cuda")
+        p.resident_target_xyz_dev(tx)
+    tx = tx.cpu().numpy()
+    res = []
+    for local in (1, 0):
+        with pkg.PointsTransfer(device=0, k_hint=k) as p:
+            p.set_param("local_ids", local)
+            p.build_synth(n_total, seed, slab_axis=0, slab_lo=lo, slab_hi=hi)
+            n = p.num_source
+            p.set_targets(tx)
+            idx = torch.empty((mm, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((mm, k), dtype=torch.float64, device="cuda")
+            c_ = torch.empty((mm, 3), dtype=torch.float32, device="cuda"); n_ = torch.empty((mm, 3), dtype=torch.float32, device="cuda")
+            p.query_blend_resident_dev(k, pkg.BLEND_MEAN, idx, d2, c_, n_)
+            torch.cuda.synchronize()
+            res.append((n, idx.cpu().numpy().view(np.uint32), d2.cpu().numpy(), c_.cpu().numpy(), n_.cpu().numpy()))
+    a, b = res
+    assert a[0] == b[0] and abs(a[0] - n_total / 8) < 1e-3 * n_total and mm > 0
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.abs(a[3] - b[3]).max() / 255.0 <= TOL and np.abs(a[4] - b[4]).max() <= TOL      # (one table gathered by position, the other by index: the same records)
+    for r in np.arange(0, mm, max(1, mm // 12))[:12]:
+        for j in range(k):
+            pt = oracle.synth_xyz(seed, 0, 1, i0=int(a[1][r, j]))[:, 0].astype(np.float64)
+            assert lo <= pt[0] < hi
+            d = tx[:, r].astype(np.float64) - pt
+            assert (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2] == a[2][r, j]
+
+
 def test_rccl_communicator_world_of_one(pkg, oracle):
     """librccl is loaded and a communicator of ONE rank comes up on this GPU (what the multi-GPU path runs on every rank before
     its first exchange); with a world of one the exchange is a no-op that leaves the lists untouched."""
