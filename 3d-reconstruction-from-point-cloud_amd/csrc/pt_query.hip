@@ -635,11 +635,10 @@ __global__ __launch_bounds__(WG, HIER ? (KPL == 4 ? 3 : 4) : 1) void knn_kernel(
 // Why a third kernel: the group kernel keeps eight targets per wave in lockstep, and in a dense cell every step of eight records
 // ends in the insertion path for SOME group (k ln(n / k) insertions per target, ~100 VALU instructions each at k = 32, seven
 // groups idle meanwhile): measured on the clustered generator it looks at 1e11 records/s whatever the index offers.  Here the
-// whole wave serves one target: 64 records per step with wave-uniform control flow; the sorted list lives one entry per lane
-// (rank i in lane i), so an insertion is one compare and one wave_shr:1 shift for the whole list (~12 instructions), and the
-// limit is a scalar.  Cells, shells, blocks and the rows of refined nodes are looked up 64 at a time, one per lane.
-// Same order, same bounds, same results as the group kernel (exact); k <= 64.
-constexpr int DPP_WAVE_SHR1 = 0x138;     // wave_shr:1: lane i <- lane i - 1 across the wave (lane 0 reads 0)
+// whole wave serves one target: 64 records per step with wave-uniform control flow; the k best live one entry per lane -- an
+// unsorted pool whose k-th smallest key, found by pivoting, is the scalar limit (see WaveScan: THE LIST) -- and are sorted once, at
+// the end.  Cells, shells, blocks and the rows of refined nodes are looked up 64 at a time, one per lane.
+// Same order, same bounds, same results as the group kernel (exact); k <= 32 (PT_MAX_K).
 constexpr int WV_RING_MAX = 31;          // shells are walked up to this ring at most (then the blocks are swept)
 constexpr uint32_t WV_RUN = 16;          // consecutive workgroups (64 targets) that share an XCD
 
@@ -681,7 +680,7 @@ struct WaveScan {
   const Rec* __restrict__ src;
   const uint32_t* __restrict__ nodes;
   double q[3], u[3], h2;       // the target, its position in cell units, squared cell side: wave-uniform
-  double ld;                   // my entry of the sorted list: lane i holds rank i
+  double ld;                   // my entry of the pool of the k best (+inf, NOIDX: none); after finish(): lane i holds rank i
   uint32_t li;
   double lim_d, bnd_d;         // acceptance limit = min(entry of rank k-1, caller's bound): wave-uniform
   uint32_t lim_i;
@@ -696,11 +695,11 @@ struct WaveScan {
   float qf[3], lim32;
   __device__ __forceinline__ void set_lim32() { lim32 = (float)(lim_d * 1.00000095367431640625) + 1e-30f; }
   int k, lane;
-  // candidates set aside (k >= PEND_MIN_K): this wave's 64 slots in LDS and how many are taken (wave-uniform); see offer()
+  // candidates set aside: this wave's 64 slots in LDS and how many are taken (wave-uniform); see offer()
   uint4* pend;                 // slot: (d2 low word, d2 high word, index, -)
   uint32_t npend;
 #ifdef PT_VISITS
-  uint32_t nv = 0, nn = 0, nmerge = 0;     // instrumented build: steps of 64 records, nodes entered, sort-merges
+  uint32_t nv = 0, nn = 0, nmerge = 0;     // instrumented build: steps of 64 records, nodes entered, selections (sort-merges until round 4)
 #endif
 
   // THE LIST (round 4, second form).  Rounds 2 - 4 kept the k best SORTED across the lanes and paid a 27-stage bitonic sort-merge (361 VALU

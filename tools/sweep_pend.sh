@@ -1,4 +1,6 @@
 #!/bin/bash
+# (rounds 2 - 4: the sorted list with sort-merges.  The final tree of round 4 keeps an unsorted pool; the one parameter left is -DPT_PEND_FLUSH,
+#  swept with `make ab NAME=pf24 DEF=-DPT_PEND_FLUSH=24` and tools/ab_wave.sh -- DESIGN.md section 10, item 10.)
 # dev probe: the wave kernel's selection parameters (-DPT_MERGE_MIN / -DPT_PEND_FLUSH / -DPT_PEND_MIN_K) on the clustered generator.
 #   bash tools/sweep_pend.sh m20f44:"-DPT_MERGE_MIN=20 -DPT_PEND_FLUSH=44" none:"-DPT_PEND_MIN_K=99" ...   (builds here, then: gpurun -- 'bash tools/sweep_pend.sh run')
 set -e
