@@ -841,8 +841,10 @@ __global__ __launch_bounds__(WG) void uniform_probe_kernel(Loader in, GridParams
     const uint32_t blk = pt_block_id(gp.mdim, cx, cy, cz);
     same += (uint32_t)__popcll(__ballot(blk == (uint32_t)__builtin_amdgcn_readfirstlane((int)blk))) - 1u;
     atomicAdd(&blk_cnt[blk], 1u);                       // (n / 64 atomics over nblocks addresses: ~30 per address)
-    const uint32_t cib = (uint32_t)((cx & 7) | ((cy & 7) << 3) | ((cz & 7) << 6));
-    atomicOr(&cell_bits[(size_t)blk * 16 + (cib >> 5)], 1u << (cib & 31u));      // which of the block's 512 cells the sample has seen
+    if (((i / POOL_SAMPLE_RUN) & 3u) == 0u) {           // (every fourth run of the sample: a quarter of the scattered atomics tells the cells apart just as well)
+      const uint32_t cib = (uint32_t)((cx & 7) | ((cy & 7) << 3) | ((cz & 7) << 6));
+      atomicOr(&cell_bits[(size_t)blk * 16 + (cib >> 5)], 1u << (cib & 31u));    // which of the block's 512 cells the sample has seen
+    }
   }
   if ((threadIdx.x & 63) == 0 && same) atomicAdd(&acc[3], (unsigned long long)same);   // (every lane of a wave counted the same ballots)
 }
@@ -887,13 +889,13 @@ __global__ __launch_bounds__(WG) void uniform_check_kernel(GridParams gp, OccBox
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const uint4 w = bits[i]; u += __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w); }
     float a = (float)cov_b;
-    const float fs = (float)sb, fu = (float)u;
+    const float fs = 0.25f * (float)sb, fu = fminf((float)u, 0.25f * (float)sb);      // (the cells were marked by every fourth run of the sample)
     if (fu < fs && a * (1.f - __expf(-fs / a)) > fu) {      // fewer distinct cells than an even spread over the whole block would show: solve for a
       float lo = fu, hi = a;
       for (int it = 0; it < 14; ++it) { const float mid = 0.5f * (lo + hi); if (mid * (1.f - __expf(-fs / mid)) < fu) lo = mid; else hi = mid; }
       a = hi;
     }
-    occ = a * (1.f - __expf(-(float)stride * fs / a));
+    occ = a * (1.f - __expf(-(float)stride * (float)sb / a));
   }
   }
 #pragma unroll
