@@ -414,6 +414,7 @@ int rebuild(pt_ctx* c) {
       }
       const double occ_ub = (double)c->h_bbox[8] / 16.0;
       const double rho_lb = occ_ub > 0.0 ? (double)c->n / occ_ub : 0.0;
+      if (getenv("PT_DEBUG_PRESORT")) fprintf(stderr, "uniform probe: flag %u chi2 %.1f dof %.0f same-block %llu\n", c->h_counter[11], (double)c->h_bbox[6] / 1024.0, (double)c->h_bbox[7], (unsigned long long)c->h_bbox[9]);
       if (getenv("PT_DEBUG_PRESORT")) fprintf(stderr, "presort probe: grid %d %d %d h %.6g occ_ub %.0f rho_lb %.2f iters %d uniform %d\n", c->gp.dim[0], c->gp.dim[1], c->gp.dim[2], c->gp.h, occ_ub, rho_lb, presort_iters, (int)c->uniform_seen);
       if (c->presort_refine && !c->uniform_seen && !c->st.ordered_input && presort_iters < 3 && rho_lb > 1.5 * c->rho) {
         const double h_old = c->gp.h;

@@ -841,20 +841,39 @@ __global__ __launch_bounds__(WG) void uniform_probe_kernel(Loader in, GridParams
     const uint32_t blk = pt_block_id(gp.mdim, cx, cy, cz);
     same += (uint32_t)__popcll(__ballot(blk == (uint32_t)__builtin_amdgcn_readfirstlane((int)blk))) - 1u;
     atomicAdd(&blk_cnt[blk], 1u);                       // (n / 64 atomics over nblocks addresses: ~30 per address)
-    if (((i / POOL_SAMPLE_RUN) & 3u) == 0u) {           // (every fourth run of the sample: a quarter of the scattered atomics tells the cells apart just as well)
-      const uint32_t cib = (uint32_t)((cx & 7) | ((cy & 7) << 3) | ((cz & 7) << 6));
-      atomicOr(&cell_bits[(size_t)blk * 16 + (cib >> 5)], 1u << (cib & 31u));    // which of the block's 512 cells the sample has seen
-    }
+    const uint32_t cib = (uint32_t)((cx & 7) | ((cy & 7) << 3) | ((cz & 7) << 6));
+    atomicOr(&cell_bits[(size_t)blk * 16 + (cib >> 5)], 1u << (cib & 31u));      // which of the block's 512 cells the sample has seen
   }
   if ((threadIdx.x & 63) == 0 && same) atomicAdd(&acc[3], (unsigned long long)same);   // (every lane of a wave counted the same ballots)
 }
 // the macro blocks' sample counts = sums of their 512 blocks' (one atomic per sample point on <= 1024 addresses cost 4 ms at 1e9 points)
-__global__ __launch_bounds__(WG) void uniform_macro_kernel(const uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ macro_cnt) {
+// A block is INTERIOR when all of its cells lie inside the occupied box shrunk by one cell: the cloud's outermost cell layers are filled to
+// whatever fraction its extent leaves of them, and a block that owns such a layer (or only a sliver of the box) misses its expected count by
+// tens of percent -- at 167 sample points per block (64 M points, rho 6) the 2500 face blocks alone tripled the chi-square sum of a uniform
+// cloud.  The chi-square is taken over interior blocks against the mean of their macro block's interior blocks.
+__device__ inline bool uniform_interior(const GridParams& gp, const OccBox& ob, uint32_t b) {
+  const uint32_t macro = b >> 9, m9 = b & 511u;
+  const int mx = (int)(macro % (uint32_t)gp.mdim[0]), my = (int)((macro / (uint32_t)gp.mdim[0]) % (uint32_t)gp.mdim[1]), mz = (int)(macro / (uint32_t)(gp.mdim[0] * gp.mdim[1]));
+  const int c0[3] = {(mx * 8 + (int)((m9 & 1u) | ((m9 >> 2) & 2u) | ((m9 >> 4) & 4u))) * 8, (my * 8 + (int)(((m9 >> 1) & 1u) | ((m9 >> 3) & 2u) | ((m9 >> 5) & 4u))) * 8,
+                     (mz * 8 + (int)(((m9 >> 2) & 1u) | ((m9 >> 4) & 2u) | ((m9 >> 6) & 4u))) * 8};
+  bool in = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) in = in && c0[a] >= ob.lo[a] + 1 && c0[a] + 8 <= ob.hi[a] - 1;
+  return in;
+}
+__global__ __launch_bounds__(WG) void uniform_macro_kernel(GridParams gp, OccBox ob, const uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ macro_cnt,
+                                                           uint32_t* __restrict__ macro_int, uint32_t* __restrict__ macro_nint) {
   __shared__ uint32_t wsum[4];
-  const uint32_t v = blk_cnt[(size_t)blockIdx.x * PT_MACRO_BLOCKS + threadIdx.x] + blk_cnt[(size_t)blockIdx.x * PT_MACRO_BLOCKS + WG + threadIdx.x];
-  uint32_t tot;
-  (void)block_excl_scan(v, wsum, tot);
-  if (threadIdx.x == 0) macro_cnt[blockIdx.x] = tot;
+  const uint32_t b0 = blockIdx.x * PT_MACRO_BLOCKS + threadIdx.x, b1 = b0 + WG;
+  const uint32_t v0 = blk_cnt[b0], v1 = blk_cnt[b1];
+  const bool i0 = uniform_interior(gp, ob, b0), i1 = uniform_interior(gp, ob, b1);
+  uint32_t tot, tin, nin;
+  (void)block_excl_scan(v0 + v1, wsum, tot);
+  __syncthreads();
+  (void)block_excl_scan((i0 ? v0 : 0u) + (i1 ? v1 : 0u), wsum, tin);
+  __syncthreads();
+  (void)block_excl_scan((uint32_t)i0 + (uint32_t)i1, wsum, nin);
+  if (threadIdx.x == 0) { macro_cnt[blockIdx.x] = tot; macro_int[blockIdx.x] = tin; macro_nint[blockIdx.x] = nin; }
 }
 // Two tests per block against e = (its macro block's sample count) x (its share of the macro's occupied cells): a MAXIMUM test -- more
 // than e + 6 sqrt(e) + 8 sample points is a clump -- and the block's term (s - e)^2 / e of a CHI-SQUARE sum over all blocks with e >= 4,
@@ -865,7 +884,8 @@ __global__ __launch_bounds__(WG) void uniform_macro_kernel(const uint32_t* __res
 // says nothing: a = all of the block's cells, the cautious end); the m = stride x s points the block really holds then occupy
 // a (1 - exp(-m / a)) cells.  n over the sum estimates the points per occupied cell the sort would count, which is what the choice of the cell
 // size goes by (pt_api.hip, rebuild) -- from below wherever the sample is thin, so that a refinement it suggests is one the count would ask for.
-__global__ __launch_bounds__(WG) void uniform_check_kernel(GridParams gp, OccBox ob, const uint32_t* __restrict__ macro_cnt, const uint32_t* __restrict__ blk_cnt,
+__global__ __launch_bounds__(WG) void uniform_check_kernel(GridParams gp, OccBox ob, const uint32_t* __restrict__ macro_cnt, const uint32_t* __restrict__ macro_int,
+                                                           const uint32_t* __restrict__ macro_nint, const uint32_t* __restrict__ blk_cnt,
                                                            const uint32_t* __restrict__ cell_bits, uint32_t nblocks, uint32_t stride, uint32_t* flag, unsigned long long* acc) {
   const uint32_t b = blockIdx.x * WG + threadIdx.x;
   float term = 0.f, occ = 0.f;
@@ -882,20 +902,23 @@ __global__ __launch_bounds__(WG) void uniform_check_kernel(GridParams gp, OccBox
   const double e = cov_m > 0.0 ? (double)macro_cnt[macro] * cov_b / cov_m : 0.0;
   const double sb = (double)blk_cnt[b];
   if (sb > e + 6.0 * sqrt(e) + 8.0) atomicOr(flag, 1u);
-  if (e >= 4.0) { term = (float)((sb - e) * (sb - e) / e); used = 1; }
+  if (uniform_interior(gp, ob, b)) {
+    const double ei = (double)macro_int[macro] / (double)max(macro_nint[macro], 1u);      // the mean of the macro block's interior blocks
+    if (ei >= 4.0) { term = (float)((sb - ei) * (sb - ei) / ei); used = 1; }
+  }
   if (sb > 0.0 && cov_b > 0.0) {
     uint32_t u = 0;
     const uint4* bits = reinterpret_cast<const uint4*>(cell_bits + (size_t)b * 16);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const uint4 w = bits[i]; u += __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w); }
     float a = (float)cov_b;
-    const float fs = 0.25f * (float)sb, fu = fminf((float)u, 0.25f * (float)sb);      // (the cells were marked by every fourth run of the sample)
+    const float fs = (float)sb, fu = (float)u;
     if (fu < fs && a * (1.f - __expf(-fs / a)) > fu) {      // fewer distinct cells than an even spread over the whole block would show: solve for a
       float lo = fu, hi = a;
       for (int it = 0; it < 14; ++it) { const float mid = 0.5f * (lo + hi); if (mid * (1.f - __expf(-fs / mid)) < fu) lo = mid; else hi = mid; }
       a = hi;
     }
-    occ = a * (1.f - __expf(-(float)stride * (float)sb / a));
+    occ = a * (1.f - __expf(-(float)stride * fs / a));
   }
   }
 #pragma unroll
@@ -1369,7 +1392,9 @@ void pt_launch_uniform_probe(const GridParams& gp, const T* x, const T* y, const
   uint32_t* macro_cnt = scratch + nblocks;
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(scratch + pt_uniform_probe_acc_offset(nblocks));
   uint32_t* cell_bits = scratch + pt_uniform_probe_acc_offset(nblocks) + 8;      // 16 words per block, 16-byte aligned (the offset is a multiple of four words, the scratch an allocation of its own)
-  (void)hipMemsetAsync(scratch, 0, sizeof(uint32_t) * ((size_t)pt_uniform_probe_acc_offset(nblocks) + 8 + (size_t)nblocks * 16), s);
+  uint32_t* macro_int = cell_bits + (size_t)nblocks * 16;                         // per macro block: the sample points of its interior blocks, and how many those are
+  uint32_t* macro_nint = macro_int + nmacro;
+  (void)hipMemsetAsync(scratch, 0, sizeof(uint32_t) * ((size_t)pt_uniform_probe_acc_offset(nblocks) + 8 + (size_t)nblocks * 16 + 2 * (size_t)nmacro), s);
   (void)hipMemsetAsync(flag, 0, sizeof(uint32_t), s);
   if (!n) return;
   PlanarLoader<T> pl{x, y, z, nullptr};
@@ -1380,10 +1405,10 @@ void pt_launch_uniform_probe(const GridParams& gp, const T* x, const T* y, const
   const uint32_t gs = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((runs + stride - 1) / stride, 1), 4096);
   hipLaunchKernelGGL((uniform_probe_kernel<PlanarLoader<T>>), dim3(gs), dim3(WG), 0, s, pl, gp, n, stride, blk_cnt, cell_bits, acc);
   static_assert(PT_MACRO_BLOCKS == 2 * WG, "two blocks per thread in the macro sums");
-  hipLaunchKernelGGL(uniform_macro_kernel, dim3(nmacro), dim3(WG), 0, s, blk_cnt, macro_cnt);
   OccBox ob;
   for (int a = 0; a < 3; ++a) { ob.lo[a] = occ_lo[a]; ob.hi[a] = occ_hi[a]; }
-  hipLaunchKernelGGL(uniform_check_kernel, dim3((nblocks + WG - 1) / WG), dim3(WG), 0, s, gp, ob, macro_cnt, blk_cnt, cell_bits, nblocks, stride, flag, acc);
+  hipLaunchKernelGGL(uniform_macro_kernel, dim3(nmacro), dim3(WG), 0, s, gp, ob, blk_cnt, macro_cnt, macro_int, macro_nint);
+  hipLaunchKernelGGL(uniform_check_kernel, dim3((nblocks + WG - 1) / WG), dim3(WG), 0, s, gp, ob, macro_cnt, macro_int, macro_nint, blk_cnt, cell_bits, nblocks, stride, flag, acc);
 }
 template void pt_launch_uniform_probe<float>(const GridParams&, const float*, const float*, const float*, uint32_t, const int*, const int*, uint32_t*, uint32_t*, hipStream_t);
 template void pt_launch_uniform_probe<__half>(const GridParams&, const __half*, const __half*, const __half*, uint32_t, const int*, const int*, uint32_t*, uint32_t*, hipStream_t);

@@ -56,7 +56,7 @@ const Rec* pt_launch_grid_sort(const GridParams& gp, const T* x, const T* y, con
                                Rec* out_final, Rec* tmp, uint32_t* cell_start, const SortTables& tb, bool do_finalize, hipStream_t s,
                                uint64_t* bbox6_verify = nullptr);   // two-level sorts: pass 1's histogram also reduces the exact bbox into it
 // does a 1/64 sample of the cloud sit in the grid's blocks the way a uniform cloud would (pooled pass 2 on the FIRST build)?  scratch:
-// pt_uniform_probe_acc_offset(nblocks) + 8 + 16 nblocks words (the last part: one bit per cell the sample has seen); *flag (device) = 1 when some block holds far more sample points than its macro block's
+// pt_uniform_probe_acc_offset(nblocks) + 8 + 16 nblocks + 2 nblocks / 512 words (one bit per cell the sample has seen; two words per macro block); *flag (device) = 1 when some block holds far more sample points than its macro block's
 // count predicts; the three 64-bit words at scratch + offset: chi-square sum over the blocks (x 1024, fixed point), how many blocks it is over,
 // an estimate of the number of cells the cloud occupies on this grid (x 16), and how many sample points fell into the block of their wave's
 // first point (64 consecutive points: a cloud stored in spatial order gives itself away)
