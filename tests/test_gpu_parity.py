@@ -807,11 +807,14 @@ def test_first_build_takes_its_cell_size_from_the_sample(pkg, oracle):
         assert u["ordered_input"] == 0 and u["uniform_probe"] == 1 and u["n_sorts"] == 1 and u["presort_refine"] == 0 and u["pass2_pooled"] == 1, u
 
 
-def test_a_sample_that_lies_about_the_occupancy_is_overruled_by_the_count(pkg, oracle):
+@pytest.mark.parametrize("cpp", [2, 8])
+def test_a_sample_that_lies_about_the_occupancy_is_overruled_by_the_count(pkg, oracle, cpp):
     """The first build's sample is every 16th run of 256 consecutive points.  Here exactly those runs sit in a small cube and everything else
     is uniform: the sample says "a clump, few cells occupied -- refine", the sampled bounding box is wrong as well, and the pooled regions are
     sized for a clump.  Every guess is verified by the build that uses it: the box is found wrong and the build starts over on the exact one,
-    the sort's own count of occupied cells bounds what the sample's refinement may leave behind, and the search is the oracle's."""
+    the sort's own count of occupied cells bounds what the sample's refinement may leave behind -- with the usual limit of two cells per point
+    the refined grid is fine but legal, with eight (cpp = 8) its cells hold a fraction of rho and the sample's answer is thrown away
+    (presort_refine < 0: grid from the box, exact passes) -- and the search is the oracle's."""
     rng = np.random.default_rng(98)
     n, m, k = 3_000_000, 3000, 8
     src = rng.random((3, n), dtype=np.float32)
@@ -822,15 +825,17 @@ def test_a_sample_that_lies_about_the_occupancy_is_overruled_by_the_count(pkg, o
     with pkg.PointsTransfer(device=0, k_hint=k) as p:
         p.set_param("pool_min_points", 1)
         p.set_param("guess_min_points", 100000)
+        p.set_param("refine_cells_per_point", cpp)
         p.build(src)
         st = p.stats()
         got = p.query(tgt, k)
-        keep = {f: st[f] for f in ("uniform_probe", "ordered_input", "presort_refine", "n_sorts", "bbox_guess", "rho_occupied", "n_refine")}
+        keep = {f: st[f] for f in ("uniform_probe", "ordered_input", "presort_refine", "n_sorts", "bbox_guess", "rho_occupied", "n_refine", "pass1_pooled")}
         assert st["bbox_guess"] == -1 and st["n_sorts"] >= 2 and st["ordered_input"] == 0, keep      # the sampled box was wrong: built again on the exact one
         assert st["uniform_probe"] == -1, keep                                      # ... where the sample no longer looks uniform
-        # whatever the sample made of the cell size, the count had the last word: a grid within the bounds a counted refinement keeps
-        # (below 0.4 rho the sample's answer is thrown away: presort_refine < 0)
-        assert 0.4 * 4.0 <= st["rho_occupied"] <= 8.0, keep
+        assert 0.4 * 4.0 <= st["rho_occupied"] <= 8.0, keep                         # the count had the last word
+        if cpp == 8:
+            assert st["presort_refine"] < 0 and st["n_sorts"] >= 3 and st["pass1_pooled"] == 0, keep
+            assert st["rho_occupied"] >= 3.0, keep                                  # the grid the cloud wants, from the box
         p.rebuild()
         st2 = p.stats()
         assert st2["n_sorts"] == 1 and st2["presort_refine"] == 0, st2
