@@ -19,7 +19,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,case,attrs", [(2, "uniform", 0), (3, "uniform", 0), (2, "clustered", 0), (3, "tiny", 0),
-                                              (2, "uniform", 1), (3, "uniform", 1), (3, "clustered", 1), (2, "tiny", 1)])
+                                              (2, "uniform", 1), (3, "uniform", 1), (3, "clustered", 1), (2, "tiny", 1),
+                                              (4, "clustered", 1), (5, "uniform", 0)])
 def test_slab_exchange_equals_global_knn(world, case, attrs):
     """attrs = 1: the attribute table is sharded with the slabs (pt_amd.sharding.SlabAttributes) -- every rank holds its own points'
     records only, the answers carry their candidates' records, and the blends of ALL targets equal the blend over the whole table bit
