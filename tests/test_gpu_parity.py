@@ -1441,7 +1441,8 @@ def test_streamed_source_100m_equals_resident(pkg, oracle):
 
 
 # ---- native slab exchange behind the C ABI (pt_exchange_*): same phases as the RCCL path, device copies as transport ------------
-@pytest.mark.parametrize("g,k,f64,sharded", [(2, 8, False, False), (3, 20, True, False), (5, 8, False, False), (2, 8, False, True), (3, 20, True, True), (5, 16, False, True)])
+@pytest.mark.parametrize("g,k,f64,sharded", [(2, 8, False, False), (3, 20, True, False), (5, 8, False, False), (2, 8, False, True), (3, 20, True, True), (5, 16, False, True),
+                                             (8, 8, False, True), (8, 20, True, False)])
 def test_native_exchange_on_logical_slabs(pkg, oracle, g, k, f64, sharded):
     """G contexts of one process, one slab each (equal-count quantiles along x; the last slab may hold NO targets): home search,
     then pt_exchange_merge_local -- count matrix, owner-to-owner requests, bounded answers, merge, re-blend of the completed rows.
