@@ -25,23 +25,40 @@ __global__ __launch_bounds__(XW) void xreq_kernel(const T* __restrict__ x, const
                                                   uint32_t m, int k, int axis, const double* __restrict__ bounds, int g, int me,
                                                   uint32_t* __restrict__ counts, const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor,
                                                   double* __restrict__ req, uint32_t* __restrict__ req_row) {
-  const uint32_t t = blockIdx.x * XW + threadIdx.x;
-  if (t >= m) return;
-  const double c = (double)(axis == 0 ? x[t] : (axis == 1 ? y[t] : z[t]));
-  const double kth = d2[(size_t)t * k + (k - 1)];
-  for (int s = 0; s < g; ++s) {
-    if (s == me || !slab_needed(c, kth, bounds[s], bounds[s + 1])) continue;
-    if constexpr (!FILL) {
-      atomicAdd(&counts[s], 1u);
-    } else {
-      const uint32_t pos = off[s] + atomicAdd(&cursor[s], 1u);
-      double* o = req + (size_t)pos * 4;
-      o[0] = (double)x[t]; o[1] = (double)y[t]; o[2] = (double)z[t]; o[3] = kth;
-      req_row[pos] = t;
+  // One GLOBAL atomic per workgroup and destination, not per target (round 4; measured on config 4 as eight logical slabs: the 70 k crossing
+  // targets of a rank -- one in ninety, spread evenly over the array, so a wave rarely holds two -- took their slots one by one from eight
+  // counters: 0.92 ms for each of the two passes where the bytes they read cost 0.1).  A workgroup walks a contiguous piece of the targets,
+  // counts per destination in LDS, reserves its ranges with one atomic each, and (FILL) walks the piece again handing out slots from LDS.
+  __shared__ uint32_t cnt[64], base[64];
+  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t per = ((m + gridDim.x - 1) / gridDim.x + XW - 1) / XW * XW, t0 = blockIdx.x * per, t1 = min(m, t0 + per);
+  for (uint32_t t = t0 + threadIdx.x; t < t1; t += XW) {
+    const double c = (double)(axis == 0 ? x[t] : (axis == 1 ? y[t] : z[t]));
+    const double kth = d2[(size_t)t * k + (k - 1)];
+    for (int s = 0; s < g; ++s)
+      if (s != me && slab_needed(c, kth, bounds[s], bounds[s + 1])) atomicAdd(&cnt[s], 1u);
+  }
+  __syncthreads();
+  if constexpr (!FILL) {
+    if (threadIdx.x < (uint32_t)g && cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], cnt[threadIdx.x]);
+  } else {
+    if (threadIdx.x < (uint32_t)g) { base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], cnt[threadIdx.x]) : 0u; cnt[threadIdx.x] = 0; }
+    __syncthreads();
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += XW) {
+      const double c = (double)(axis == 0 ? x[t] : (axis == 1 ? y[t] : z[t]));
+      const double kth = d2[(size_t)t * k + (k - 1)];
+      for (int s = 0; s < g; ++s) {
+        if (s != me && slab_needed(c, kth, bounds[s], bounds[s + 1])) {
+          const uint32_t pos = off[s] + base[s] + atomicAdd(&cnt[s], 1u);
+          double* o = req + (size_t)pos * 4;
+          o[0] = (double)x[t]; o[1] = (double)y[t]; o[2] = (double)z[t]; o[3] = kth;
+          req_row[pos] = t;
+        }
+      }
     }
   }
 }
-
 template <class T>
 __global__ __launch_bounds__(XW) void xunpack_kernel(const double* __restrict__ rreq, uint32_t r, T* __restrict__ xyz, double* __restrict__ bound) {
   const uint32_t i = blockIdx.x * XW + threadIdx.x;
@@ -166,8 +183,17 @@ __global__ __launch_bounds__(XW) void ascending_kernel(const uint32_t* __restric
 }
 
 __global__ __launch_bounds__(XW) void xflag_rows_kernel(const uint8_t* __restrict__ flags, uint32_t m, uint32_t* __restrict__ rows, uint32_t* __restrict__ count) {
-  const uint32_t t = blockIdx.x * XW + threadIdx.x;
-  if (t < m && flags[t]) rows[atomicAdd(count, 1u)] = t;
+  // (as xreq_kernel: a workgroup counts the flagged rows of its piece in LDS, takes its range with ONE atomic and hands the slots out from LDS;
+  //  70 k rows of a rank one by one from one counter took 0.73 ms)
+  __shared__ uint32_t cnt, base;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const uint32_t per = ((m + gridDim.x - 1) / gridDim.x + XW - 1) / XW * XW, t0 = blockIdx.x * per, t1 = min(m, t0 + per);
+  for (uint32_t t = t0 + threadIdx.x; t < t1; t += XW) if (flags[t]) atomicAdd(&cnt, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) { base = cnt ? atomicAdd(count, cnt) : 0u; cnt = 0; }
+  __syncthreads();
+  for (uint32_t t = t0 + threadIdx.x; t < t1; t += XW) if (flags[t]) rows[base + atomicAdd(&cnt, 1u)] = t;
 }
 
 }  // namespace
@@ -178,8 +204,9 @@ template <class T>
 void pt_launch_xreq(bool fill, const T* x, const T* y, const T* z, const double* d2, uint32_t m, int k, int axis, const double* bounds_dev, int g, int me,
                     uint32_t* counts, const uint32_t* off, uint32_t* cursor, double* req, uint32_t* req_row, hipStream_t s) {
   if (!m) return;
-  if (fill) hipLaunchKernelGGL((xreq_kernel<T, true>), xgrid(m), dim3(XW), 0, s, x, y, z, d2, m, k, axis, bounds_dev, g, me, counts, off, cursor, req, req_row);
-  else hipLaunchKernelGGL((xreq_kernel<T, false>), xgrid(m), dim3(XW), 0, s, x, y, z, d2, m, k, axis, bounds_dev, g, me, counts, off, cursor, req, req_row);
+  const dim3 grid(std::min<uint32_t>((m + XW - 1) / XW, 2048u));       // a piece of the targets per workgroup (xreq_kernel)
+  if (fill) hipLaunchKernelGGL((xreq_kernel<T, true>), grid, dim3(XW), 0, s, x, y, z, d2, m, k, axis, bounds_dev, g, me, counts, off, cursor, req, req_row);
+  else hipLaunchKernelGGL((xreq_kernel<T, false>), grid, dim3(XW), 0, s, x, y, z, d2, m, k, axis, bounds_dev, g, me, counts, off, cursor, req, req_row);
 }
 template void pt_launch_xreq<float>(bool, const float*, const float*, const float*, const double*, uint32_t, int, int, const double*, int, int, uint32_t*,
                                     const uint32_t*, uint32_t*, double*, uint32_t*, hipStream_t);
@@ -198,7 +225,7 @@ void pt_launch_xmerge(const uint32_t* rows, uint32_t cnt, const uint32_t* bi, co
 }
 void pt_launch_xflag_rows(const uint8_t* flags, uint32_t m, uint32_t* rows, uint32_t* count, hipStream_t s) {
   if (!m) return;
-  hipLaunchKernelGGL(xflag_rows_kernel, xgrid(m), dim3(XW), 0, s, flags, m, rows, count);
+  hipLaunchKernelGGL(xflag_rows_kernel, dim3(std::min<uint32_t>((m + XW - 1) / XW, 2048u)), dim3(XW), 0, s, flags, m, rows, count);
 }
 
 static inline dim3 xgrid64(size_t n) { return dim3((unsigned)((n + XW - 1) / XW)); }
