@@ -317,10 +317,12 @@ def main():
                     help="N > 1: native = pt_exchange_merge_dev (RCCL behind the C ABI: one count-matrix all-gather, grouped send/recv) -- if its "
                          "communicator does not come up the run FAILS (non-zero exit), it never changes protocol by itself; "
                          "torch = the torch.distributed all-gather protocol of sharding.py (what the gloo CPU tests drive), an explicit choice")
-    ap.add_argument("--attributes", default="sharded", choices=["sharded", "replicated"],
+    ap.add_argument("--attributes", default="auto", choices=["auto", "sharded", "replicated"],
                     help="N > 1 with the native exchange: sharded = every rank generates its slab in index order, keeps positions in its records "
-                         "and the attribute records of its OWN points only (16 n / N bytes; the answers carry their candidates' records); "
-                         "replicated = every rank holds the whole 16 n-byte table (what --exchange torch always does)")
+                         "and the attribute records of its OWN points only (16 n / N bytes; the answers carry their candidates' records; the lists "
+                         "are translated to global indices by one more pass, ~ 1 ms per 50 M neighbours); replicated = every rank holds the whole "
+                         "16 n-byte table (what --exchange torch always does); auto = replicated while the whole table is under a quarter of the "
+                         "GPU's memory (config 4: 16 GB of 288), sharded beyond")
     ap.add_argument("--source-points", dest="n", type=int, default=0, help="override the workload's source count (rehearsals)")
     ap.add_argument("--target-points", dest="m", type=int, default=0, help="override the workload's target count (rehearsals)")
     ap.add_argument("--dry-run", action="store_true",
@@ -408,7 +410,8 @@ def main():
             sx = torch.empty((3, probe.num_targets), dtype=torch.float32, device=dev)
             probe.resident_target_xyz_dev(sx)
             bounds = sharding.quantile_slab_bounds(sx[axis], world)
-    sharded_attr = native and args.attributes == "sharded"
+    hbm = torch.cuda.get_device_properties(local_rank).total_memory
+    sharded_attr = native and (args.attributes == "sharded" or (args.attributes == "auto" and 16 * n_total > hbm // 4))
     if sharded_attr:
         pt.set_param("local_ids", 1)
     if world > 1:

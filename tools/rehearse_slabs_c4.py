@@ -1,7 +1,7 @@
 """BASELINE config 4 (1B / 50M / k = 8) as G logical slabs on ONE GPU: what `bench.py --gpus G` computes, with device copies in place of RCCL
 (pt_exchange_merge_local) -- every slab generated in index order with positions in its records and its own attribute records -- compared row by
 row with the single-context run of the whole cloud: indices and distances bit for bit, blends within 1e-5.  Prints per-slab phase times.
-usage: python tools/rehearse_slabs_c4.py [G=8] [n=1e9]"""
+usage: python tools/rehearse_slabs_c4.py [G=8] [n=1e9] [sharded=1]"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -10,6 +10,7 @@ pkg = g.load_package()
 from pt_amd import sharding
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000_000
+sharded = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 m, k, seed = n // 20, 8, 0xC4
 dev = torch.device("cuda", 0)
 bounds = sharding.uniform_slab_bounds(G)
@@ -25,7 +26,7 @@ pts, xs, ii, dd, cc, nn, ids = [], [], [], [], [], [], []
 tb = tq = 0.0
 for s in range(G):
     p = pkg.PointsTransfer(device=0, k_hint=k)
-    p.set_param("local_ids", 1)
+    p.set_param("local_ids", sharded)
     p.build_synth(n, seed, slab_axis=0, slab_lo=bounds[s], slab_hi=bounds[s + 1])
     p.targets_synth(m, seed, slab_axis=0, slab_lo=bounds[s], slab_hi=bounds[s + 1])
     ml = p.num_targets
@@ -36,8 +37,8 @@ for s in range(G):
     p.rebuild(); p.query_blend_resident_dev(k, pkg.BLEND_MEAN, i_, d_, c_, n_); torch.cuda.synchronize()
     st = p.stats(); tb += st["ms_build"]; tq += st["ms_query"] + st["ms_sort_targets"]
     pts.append(p); xs.append(x); ii.append(i_); dd.append(d_); cc.append(c_); nn.append(n_); ids.append(t)
-print("%d slabs built and searched: sources %s, targets %s; mean build %.2f ms, mean target sort + search %.2f ms" %
-      (G, [p.num_source for p in pts], [int(x.shape[1]) for x in xs], tb / G, tq / G), flush=True)
+print("attributes %s; %d slabs built and searched: sources %s, targets %s; mean build %.2f ms, mean target sort + search %.2f ms" %
+      ("sharded" if sharded else "replicated", G, [p.num_source for p in pts], [int(x.shape[1]) for x in xs], tb / G, tq / G), flush=True)
 for rnd in range(3):                                        # the third round is the steady state (every buffer allocated)
     tb = tq = 0.0
     for s, p in enumerate(pts):
