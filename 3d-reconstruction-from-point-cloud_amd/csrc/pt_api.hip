@@ -66,6 +66,7 @@ struct pt_ctx {
   // slabs (round 4): "local_ids" asked for AND the slab's gidx strictly ascending -> the records carry the point's POSITION in the slab's arrays
   // (same order as the global index), the attribute table may be the slab's own n records (attr_local), finished lists are translated through gidx
   bool want_local_ids = false, local_mode = false, attr_local = false;
+  uint64_t synth_total = 0;    // a generated slab in local mode: the GENERATOR's point count (n_total is the slab's own then: its attribute table's length), which the clustered target generator needs
   uint64_t guess_min_points = 8u << 20;   // clouds at least this large lay their grid out from a sampled bounding box
   bool bbox_guess_ok = true;   // big clouds: lay the grid out from a sampled bounding box (cleared when a guess failed; reset by an upload)
   bool stream_bounds = true;   // pt_stream_query: later chunks are searched under the targets' current k-th distances and skipped when out of reach ("stream_bounds", a measurement switch)
@@ -1099,7 +1100,7 @@ int pt_build_soa_indexed(pt_ctx* c, const void* xyz, int xyz_type, const uint32_
     HIPCHK(c, hipMemcpyAsync(c->h_counter + 1, flag, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->h_counter[1]) return fail(c, PT_ERR_ARG, "local_ids: the slab's global indices must be strictly ascending (positions then order like indices)");
-    c->local_mode = true;
+    c->local_mode = true; c->synth_total = 0;
     c->has_attr = false; c->attr_local = false;
   }
   if (!gidx) { c->n_total = n; c->has_attr = false; c->attr_local = false; }
@@ -1228,7 +1229,7 @@ int pt_build_synth(pt_ctx* c, uint64_t n_total, uint64_t seed, int dist, int xyz
     RES(c, c->attr, std::max<uint64_t>(n_total, 1) * sizeof(Attr));
     pt_launch_synth_attr(seed, (uint32_t)n_total, (Attr*)c->attr.p, c->stream);
   }
-  c->src_type = xyz_type; c->n = n; c->n_total = ordered ? n : n_total; c->has_gidx = slab; c->local_mode = ordered; c->attr_local = ordered; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
+  c->src_type = xyz_type; c->n = n; c->n_total = ordered ? n : n_total; c->synth_total = n_total; c->has_gidx = slab; c->local_mode = ordered; c->attr_local = ordered; c->has_attr = true; c->built = false; c->posattr_valid = false; c->bbox_guess_ok = true; c->pool_ok = true; c->pool2_ok = true; c->uniform_seen = false; c->uniform_known = false; c->hint_h = 0.0; c->in_half = keep_half; c->xyz32_valid = false;
   return rebuild(c);
 }
 
@@ -1252,7 +1253,7 @@ int pt_targets_synth(pt_ctx* c, uint64_t m_total, uint64_t seed, int dist, int x
   const bool slab = slab_axis >= 0;
   if (slab) {
     HIPCHK(c, hipMemsetAsync(c->counter.p, 0, 4, c->stream));
-    pt_launch_synth_xyz<float>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, nullptr, nullptr, nullptr, nullptr, (uint32_t*)c->counter.p, 0, f16, dist, c->n_total, m_total, c->stream);
+    pt_launch_synth_xyz<float>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, nullptr, nullptr, nullptr, nullptr, (uint32_t*)c->counter.p, 0, f16, dist, (c->local_mode && c->synth_total) ? c->synth_total : c->n_total, m_total, c->stream);
     HIPCHK(c, hipMemcpyAsync(c->h_counter, c->counter.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     m = *c->h_counter;
@@ -1261,8 +1262,8 @@ int pt_targets_synth(pt_ctx* c, uint64_t m_total, uint64_t seed, int dist, int x
   RES(c, c->t_gidx, std::max<uint64_t>(m, 1) * sizeof(uint32_t));
   RES(c, c->t_xyz, std::max<uint64_t>(m, 1) * 3 * tsize(xyz_type));
   uint32_t* g = (uint32_t*)c->t_gidx.p;
-  if (xyz_type == PT_F32) { float* x = (float*)c->t_xyz.p; pt_launch_synth_xyz<float>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, x, x + m, x + 2 * m, g, (uint32_t*)c->counter.p, (uint32_t)m, f16, dist, c->n_total, m_total, c->stream); }
-  else { double* x = (double*)c->t_xyz.p; pt_launch_synth_xyz<double>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, x, x + m, x + 2 * m, g, (uint32_t*)c->counter.p, (uint32_t)m, f16, dist, c->n_total, m_total, c->stream); }
+  if (xyz_type == PT_F32) { float* x = (float*)c->t_xyz.p; pt_launch_synth_xyz<float>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, x, x + m, x + 2 * m, g, (uint32_t*)c->counter.p, (uint32_t)m, f16, dist, (c->local_mode && c->synth_total) ? c->synth_total : c->n_total, m_total, c->stream); }
+  else { double* x = (double*)c->t_xyz.p; pt_launch_synth_xyz<double>(seed, 1, (uint32_t)m_total, slab_axis, slab_lo, slab_hi, x, x + m, x + 2 * m, g, (uint32_t*)c->counter.p, (uint32_t)m, f16, dist, (c->local_mode && c->synth_total) ? c->synth_total : c->n_total, m_total, c->stream); }
   c->tgt_type = xyz_type; c->m = m; c->t_has_gidx = true;
   return finish(c);
 }

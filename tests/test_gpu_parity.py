@@ -1632,14 +1632,16 @@ def test_generated_slab_at_c4_scale_local_ids_equal_global_ids(pkg, oracle):
             assert (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2] == a[2][r, j]
 
 
-@pytest.mark.parametrize("sharded", [1, 0])
-def test_config4_as_eight_logical_slabs_equals_the_single_context_run(sharded):
+@pytest.mark.parametrize("sharded,work", [(1, "C4"), (0, "C4"), (1, "C5")])
+def test_config4_as_eight_logical_slabs_equals_the_single_context_run(sharded, work):
     """BASELINE config 4 at FULL size the way `bench.py --gpus 8` computes it -- eight slabs of the 1e9-point cloud generated, built, searched
     and exchanged (pt_exchange_merge_local: the RCCL path with device copies as transport), with sharded and with replicated attributes --
     against the single-context run of the whole cloud: all 50 M rows, indices and distances bit for bit, blends within 1e-5
-    (tools/rehearse_slabs_c4.py; it also prints the per-slab times DESIGN.md section 7's table quotes)."""
+    (tools/rehearse_slabs_c4.py; it also prints the per-slab times DESIGN.md section 7's table quotes).  C5: the same for BASELINE config 5 --
+    the clustered fp16 cloud at k = 32, equal-count slabs from a sample's quantiles; this case found the clustered TARGET generator being handed
+    the slab's point count instead of the cloud's when the slab keeps local ids)."""
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "rehearse_slabs_c4.py")
-    r = subprocess.run([sys.executable, tool, "8", "1e9", str(sharded)], capture_output=True, text=True, timeout=600,
+    r = subprocess.run([sys.executable, tool, "8", "1e9", str(sharded), work], capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-2000:]
     assert "rows that differ from the single-context run: 0 of 50000000" in r.stdout

@@ -1,7 +1,7 @@
 """BASELINE config 4 (1B / 50M / k = 8) as G logical slabs on ONE GPU: what `bench.py --gpus G` computes, with device copies in place of RCCL
 (pt_exchange_merge_local) -- every slab generated in index order with positions in its records and its own attribute records -- compared row by
 row with the single-context run of the whole cloud: indices and distances bit for bit, blends within 1e-5.  Prints per-slab phase times.
-usage: python tools/rehearse_slabs_c4.py [G=8] [n=1e9] [sharded=1]"""
+usage: python tools/rehearse_slabs_c4.py [G=8] [n=1e9] [sharded=1] [C4|C5]   (C5: the clustered fp16 cloud at k = 32, equal-count slabs from a sample's quantiles, as bench.py cuts them)"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -11,12 +11,19 @@ from pt_amd import sharding
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000_000
 sharded = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-m, k, seed = n // 20, 8, 0xC4
+work = sys.argv[4] if len(sys.argv) > 4 else "C4"
+m, k, seed = n // 20, (32 if work == "C5" else 8), (0xC5 if work == "C5" else 0xC4)
+gen = dict(dist=pkg.capi.DIST_CLUSTERED, xyz_type=pkg.F16) if work == "C5" else {}
 dev = torch.device("cuda", 0)
 bounds = sharding.uniform_slab_bounds(G)
+if work == "C5":
+    with pkg.PointsTransfer(device=0) as probe:
+        probe.build_synth(4_000_000, seed, **gen); probe.targets_synth(1_000_000, seed, **gen)
+        sx = torch.empty((3, probe.num_targets), dtype=torch.float32, device=dev); probe.resident_target_xyz_dev(sx)
+        bounds = sharding.quantile_slab_bounds(sx[0], G)
 t0 = time.time()
 ref = pkg.PointsTransfer(device=0, k_hint=k)
-ref.build_synth(n, seed); ref.targets_synth(m, seed)
+ref.build_synth(n, seed, **gen); ref.targets_synth(m, seed, **gen)
 ri = torch.empty((m, k), dtype=torch.int32, device=dev); rd = torch.empty((m, k), dtype=torch.float64, device=dev)
 rc = torch.empty((m, 3), dtype=torch.float32, device=dev); rn = torch.empty((m, 3), dtype=torch.float32, device=dev)
 ref.query_blend_resident_dev(k, pkg.BLEND_MEAN, ri, rd, rc, rn); torch.cuda.synchronize()
@@ -27,8 +34,8 @@ tb = tq = 0.0
 for s in range(G):
     p = pkg.PointsTransfer(device=0, k_hint=k)
     p.set_param("local_ids", sharded)
-    p.build_synth(n, seed, slab_axis=0, slab_lo=bounds[s], slab_hi=bounds[s + 1])
-    p.targets_synth(m, seed, slab_axis=0, slab_lo=bounds[s], slab_hi=bounds[s + 1])
+    p.build_synth(n, seed, slab_axis=0, slab_lo=bounds[s], slab_hi=bounds[s + 1], **gen)
+    p.targets_synth(m, seed, slab_axis=0, slab_lo=bounds[s], slab_hi=bounds[s + 1], **gen)
     ml = p.num_targets
     x = torch.empty((3, ml), dtype=torch.float32, device=dev); p.resident_target_xyz_dev(x)
     t = torch.empty((ml,), dtype=torch.int32, device=dev); p.resident_target_ids_dev(t)
