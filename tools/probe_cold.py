@@ -1,5 +1,6 @@
 """Cold builds of non-uniform clouds: sorts, refinements and build time of the FIRST build with and without the pre-sort refinement (dev probe).
-usage: python tools/probe_cold.py shell|clus|c5|ordered [n]"""
+usage: python tools/probe_cold.py shell|clus|c5|ordered|uniform [n]     (PT_DEBUG_PRESORT=1: the library prints what the sample said -- chi-square, degrees of freedom,
+consecutive points sharing a block, the occupancy estimate and the grid it was taken on -- to stderr, once per probe)"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np
