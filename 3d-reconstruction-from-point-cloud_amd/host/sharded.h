@@ -144,8 +144,10 @@ inline void slab_bounds(const Pieces& c, int world, int& axis, std::vector<doubl
     sx.push_back(v[0]); sy.push_back(v[1]); sz.push_back(v[2]);
     for (int a = 0; a < 3; ++a) { if (v[a] < mn[a]) mn[a] = v[a]; if (v[a] > mx[a]) mx[a] = v[a]; }
   }
-  axis = 0;
-  for (int a = 1; a < 3; ++a) if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+  // the longest axis (fewest targets near a cut) -- among axes within 10 % of each other the LAST one: the grid's macro blocks are laid out
+  // x-fastest, and slabs that keep whole x / y rows of them search 8 - 10 % faster than slabs cut along x (tools/rehearse_slabs_c4.py)
+  axis = 2;
+  for (int a = 1; a >= 0; --a) if (mx[a] - mn[a] > 1.1 * (mx[axis] - mn[axis])) axis = a;
   std::vector<double>& s = axis == 0 ? sx : (axis == 1 ? sy : sz);
   std::sort(s.begin(), s.end());
   bounds.assign((size_t)world + 1, 0.0);

@@ -1,7 +1,7 @@
 """BASELINE config 4 (1B / 50M / k = 8) as G logical slabs on ONE GPU: what `bench.py --gpus G` computes, with device copies in place of RCCL
 (pt_exchange_merge_local) -- every slab generated in index order with positions in its records and its own attribute records -- compared row by
 row with the single-context run of the whole cloud: indices and distances bit for bit, blends within 1e-5.  Prints per-slab phase times.
-usage: python tools/rehearse_slabs_c4.py [G=8] [n=1e9] [sharded=1] [C4|C5]   (C5: the clustered fp16 cloud at k = 32, equal-count slabs from a sample's quantiles, as bench.py cuts them)"""
+usage: python tools/rehearse_slabs_c4.py [G=8] [n=1e9] [sharded=1] [C4|C5] [axis=0]   (C5: the clustered fp16 cloud at k = 32, equal-count slabs from a sample's quantiles, as bench.py cuts them)"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -12,6 +12,7 @@ G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000_000
 sharded = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 work = sys.argv[4] if len(sys.argv) > 4 else "C4"
+axis = int(sys.argv[5]) if len(sys.argv) > 5 else 0          # the axis the slabs are cut along
 m, k, seed = n // 20, (32 if work == "C5" else 8), (0xC5 if work == "C5" else 0xC4)
 gen = dict(dist=pkg.capi.DIST_CLUSTERED, xyz_type=pkg.F16) if work == "C5" else {}
 dev = torch.device("cuda", 0)
@@ -20,7 +21,7 @@ if work == "C5":
     with pkg.PointsTransfer(device=0) as probe:
         probe.build_synth(4_000_000, seed, **gen); probe.targets_synth(1_000_000, seed, **gen)
         sx = torch.empty((3, probe.num_targets), dtype=torch.float32, device=dev); probe.resident_target_xyz_dev(sx)
-        bounds = sharding.quantile_slab_bounds(sx[0], G)
+        bounds = sharding.quantile_slab_bounds(sx[axis], G)
 t0 = time.time()
 ref = pkg.PointsTransfer(device=0, k_hint=k)
 ref.build_synth(n, seed, **gen); ref.targets_synth(m, seed, **gen)
@@ -34,8 +35,8 @@ tb = tq = 0.0
 for s in range(G):
     p = pkg.PointsTransfer(device=0, k_hint=k)
     p.set_param("local_ids", sharded)
-    p.build_synth(n, seed, slab_axis=0, slab_lo=bounds[s], slab_hi=bounds[s + 1], **gen)
-    p.targets_synth(m, seed, slab_axis=0, slab_lo=bounds[s], slab_hi=bounds[s + 1], **gen)
+    p.build_synth(n, seed, slab_axis=axis, slab_lo=bounds[s], slab_hi=bounds[s + 1], **gen)
+    p.targets_synth(m, seed, slab_axis=axis, slab_lo=bounds[s], slab_hi=bounds[s + 1], **gen)
     ml = p.num_targets
     x = torch.empty((3, ml), dtype=torch.float32, device=dev); p.resident_target_xyz_dev(x)
     t = torch.empty((ml,), dtype=torch.int32, device=dev); p.resident_target_ids_dev(t)
@@ -53,7 +54,7 @@ for rnd in range(3):                                        # the third round is
         st = p.stats(); tb += st["ms_build"]; tq += st["ms_query"] + st["ms_sort_targets"]
     before = [i.clone() for i in ii]
     torch.cuda.synchronize(); t1 = time.time()
-    pkg.PointsTransfer.exchange_merge_local(pts, xs, pkg.F32, k, 0, bounds, ii, dd, pkg.BLEND_MEAN, cc, nn)
+    pkg.PointsTransfer.exchange_merge_local(pts, xs, pkg.F32, k, axis, bounds, ii, dd, pkg.BLEND_MEAN, cc, nn)
     torch.cuda.synchronize(); t2 = time.time()
     changed = sum(int((b != a).any(dim=1).sum()) for a, b in zip(before, ii))
     print("round %d: per slab build %.2f ms, target sort + search %.2f ms, exchange %.2f ms (wall of all slabs in sequence / G); %d of %d rows completed by another slab" %
