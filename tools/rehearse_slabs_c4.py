@@ -1,7 +1,7 @@
 """BASELINE config 4 (1B / 50M / k = 8) as G logical slabs on ONE GPU: what `bench.py --gpus G` computes, with device copies in place of RCCL
 (pt_exchange_merge_local) -- every slab generated in index order with positions in its records and its own attribute records -- compared row by
 row with the single-context run of the whole cloud: indices and distances bit for bit, blends within 1e-5.  Prints per-slab phase times.
-usage: python tools/rehearse_slabs_c4.py [G=8] [n=1e9] [sharded=1] [C4|C5] [axis=0]   (C5: the clustered fp16 cloud at k = 32, equal-count slabs from a sample's quantiles, as bench.py cuts them)"""
+usage: python tools/rehearse_slabs_c4.py [G=8] [n=1e9] [sharded=1] [C4|C5] [axis=2]   (C5: the clustered fp16 cloud at k = 32, equal-count slabs from a sample's quantiles, as bench.py cuts them)"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -12,7 +12,7 @@ G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000_000
 sharded = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 work = sys.argv[4] if len(sys.argv) > 4 else "C4"
-axis = int(sys.argv[5]) if len(sys.argv) > 5 else 0          # the axis the slabs are cut along
+axis = int(sys.argv[5]) if len(sys.argv) > 5 else 2          # the axis the slabs are cut along (bench.py: z)
 m, k, seed = n // 20, (32 if work == "C5" else 8), (0xC5 if work == "C5" else 0xC4)
 gen = dict(dist=pkg.capi.DIST_CLUSTERED, xyz_type=pkg.F16) if work == "C5" else {}
 dev = torch.device("cuda", 0)
